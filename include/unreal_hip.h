@@ -1,0 +1,124 @@
+/* libunreal_hip.so -- C ABI of the MI355X (gfx950) UNREAL actor-learner hot path.
+ *
+ * The reference (kvas7andy/unreal, /root/reference) has no FFI of its own: the path sits behind a
+ * Python class surface and, below it, TensorFlow's op registry.  Every entry point here replaces one
+ * reference call site (cited per function, file:line under /root/reference) and is what a binding
+ * for that call would bind.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes.  ALL pointers are DEVICE pointers owned by the caller
+ *     (the Python host allocates them through PyTorch-ROCm); nothing is allocated or freed here.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream.
+ *   - return 0 = OK, -22 = invalid argument (nothing launched), -5 = launch failure.  Never throws.
+ *   - No global state; not thread-safe per buffer (one host thread per GPU by contract).
+ *   - Frames are uint8 NHWC 84x84x3 (21,168 B); a "frame index" f addresses frames + f*21168.
+ *   - Ring: actor b owns H1 = H+1 slots; absolute frame i lives in slot i % H1; per-slot metadata
+ *     arrays are [B][H1]; the current observation of actor b is slot count[b] % H1.
+ */
+#ifndef UNREAL_HIP_H
+#define UNREAL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNREAL_FRAME_BYTES 21168
+#define UNREAL_PC_CELLS 400
+/* unreal_gemm_f32 flags */
+#define UNREAL_GEMM_RELU 1
+#define UNREAL_GEMM_ACCUM 2
+#define UNREAL_GEMM_ATOMIC 4
+#define UNREAL_GEMM_RELU_MASK 8
+
+/* ---- environment (environment/maze_environment.py:50-55,98-128; environment/environment.py:88-102;
+ *      train/experience.py:63-93 add_frame; train/trainer.py:194-205,264-296 reset rules) ---------- */
+int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* pos, int* last_action,
+                     float* last_reward, int* count, uint8_t* frames, float* r_reward, int* r_action,
+                     int* r_terminal, int* r_last_action, float* r_last_reward, float* r_pc,
+                     float* out_reward, int* out_terminal, float* episode_reward, float* score_out,
+                     int* score_valid, int reset_on_terminal, int track_score, void* stream);
+int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
+                      const int* count, uint8_t* frames, void* stream);
+/* generic _calc_pixel_change on stored uint8 frames: out[n][400] = sum_{4x4x3}|new-old| / denom */
+int unreal_pixel_change_u8(int N, const uint8_t* frames, const int* idx_new, const int* idx_old,
+                           float denom, float* out, void* stream);
+
+/* ---- counter RNG (stands in for the shared numpy RandomState of main.py:213) ---------- */
+int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, double* out, void* stream);
+int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int high, int* out, void* stream);
+
+/* ---- replay sampling (train/experience.py:100-118, 121-153; train/trainer.py:427-434) ------------ */
+int unreal_replay_sample_seq(int B, int H, int H1, int L, const int* start_draw, const int* count,
+                             const int* r_terminal, int* seq_idx /*[L][B]*/, int* seq_len /*[B]*/, void* stream);
+int unreal_replay_sample_rp(int B, int H, int H1, const int* coin, const double* u, const int* count,
+                            const float* r_reward, int* rp_idx /*[B][3]*/, int* rp_class /*[B]*/, void* stream);
+
+/* ---- return scans (train/trainer.py:298-324, 354-372, 394-406), fp64 like the reference ----------- */
+int unreal_base_returns(int B, int T, const float* rewards, const float* values, const int* n_steps,
+                        const float* boot_v, const int* terminal_end, double gamma, float* R_out, float* adv_out,
+                        void* stream);
+int unreal_vr_returns(int B, int L, const int* seq_idx, const int* seq_len, const float* r_reward,
+                      const int* r_terminal, const float* boot_v, double gamma, float* R_out, void* stream);
+int unreal_pc_returns(int B, int L, const int* seq_idx, const int* seq_len, const float* r_pc,
+                      const int* r_terminal, const float* boot_qmax, double gamma_pc, float* R_out, void* stream);
+
+/* ---- rollout bookkeeping (train/experience.py:35-46; train/trainer.py:236-296; model.py:625-628) -- */
+int unreal_lar_fill(int rows, int A, const int* last_action, const float* last_reward, const int* idx, float* xcat,
+                    int ld, int col0, void* stream);
+int unreal_gather_i32(int rows, const int* src, const int* idx, int* out, void* stream);
+int unreal_rollout_advance(int B, const int* terminal_t, int* active, int* active_log_t, int* n_steps,
+                           int* terminal_end, void* stream);
+int unreal_seq_mask(int B, int T, const int* seq_len, int* mask, void* stream);
+int unreal_reset_state(int B, const int* terminal_end, float* c, float* h, void* stream);
+int unreal_ring_cur_idx(int B, int H1, const int* count, int* out /*[B]*/, void* stream);
+
+/* ---- conv encoder (model/model.py:281-289,786-787) and its gradient ------------------------------ */
+int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
+                       const float* b1, const float* W2, const float* b2, float* c1_out /*nullable [N][400][16]*/,
+                       float* f2_out /*[N][2592]*/, void* stream);
+int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,
+                       const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2, float* db2,
+                       void* stream);
+
+/* ---- dense layers: tf.matmul call sites model/model.py:314,334,423 and BasicLSTMCell 110,346-351 -- */
+int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+                    int ldb, float* C, int ldc, const float* bias, const float* mask, int ldm, int flags,
+                    int splitk, void* stream);
+int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
+                          float* c_out, float* h_out, int ld_h, void* stream);
+int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,
+                          const float* c_prev, const float* c_new, float* dpre, void* stream);
+
+/* ---- heads, sampling, losses (model/model.py:358-377, 473-516, 559-576; train/trainer.py:147-148) -- */
+int unreal_linear_small_fwd(int rows, int K, int NOUT, const float* X, int ldx, const float* W, const float* b,
+                            float* out, int ldo, void* stream);
+int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, const float* dO, int ldo,
+                            const float* W, float* dX, int lddx, int accumulate_dx, float* dW, float* db,
+                            void* stream);
+int unreal_softmax_sample(int rows, int A, float* logits_pi, int ld, const double* u, int* action, void* stream);
+int unreal_base_loss_grad(int rows, int A, const float* pi, int ld_pi, const float* v, const int* action,
+                          const float* adv, const float* R, const int* active, float entropy_beta, float grad_scale,
+                          float* dlogits, float* dv, float* losses /*[3]: policy, value, entropy*/, void* stream);
+int unreal_vr_loss_grad(int rows, const float* v, const float* R, const int* mask, float grad_scale, float* dv,
+                        float* loss, void* stream);
+int unreal_rp_loss_grad(int rows, const float* logits, const int* cls, float grad_scale, float* prob, float* dlogits,
+                        float* loss, void* stream);
+int unreal_colsum(int rows, int cols, const float* X, int ld, float* out, void* stream);
+int unreal_relu_mask(int rows, int cols, float* d, int ldd, const float* src, int lds, void* stream);
+
+/* ---- pixel-control head (model/model.py:411-443, 542-557, 805-820) -------------------------------- */
+int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const float* bv, const float* Wa,
+                         const float* ba, float* qmax, const int* action, const float* target, const int* mask,
+                         float lambda, float grad_scale, float* d_dec, float* loss, void* stream);
+int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, const float* Wv, const float* Wa,
+                         float* d_hp, float* dWv, float* dbv, float* dWa, float* dba, void* stream);
+
+/* ---- optimiser (train/rmsprop_applier.py:38-43, 83-93, 121) ---------------------------------------- */
+int unreal_grad_norm(const float* grad, long n, float* scratch /*256 floats*/, float* norm_out, void* stream);
+int unreal_rmsprop_step(float* var, float* ms, float* mom, const float* grad, long n, float lr, float decay,
+                        float momentum, float eps, float clip_norm, const float* norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,663 @@
+"""Kernel-level parity tests (GPU): every HIP kernel, called through the C ABI (ctypes), against the
+CPU oracle / a plain PyTorch fp32-or-fp64 reference on the same seeded inputs.
+
+Bars: integer / byte / index work bit-exact; floating point within the tolerance written at each
+assert (fp32 kernels vs an fp64 reference of the same op: abs 2e-5 + rel 2e-5 unless noted)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import maze as OM
+from oracle import model as M
+from oracle.experience import OracleExperience, Frame
+from oracle.rmsprop import OracleRMSProp
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from unreal_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda:0"
+
+
+def dev(a, dt=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.to(DEV).contiguous()
+
+
+def close(got, ref, atol=2e-5, rtol=2e-5, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    err = np.abs(got - ref) - (atol + rtol * np.abs(ref))
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert err.max() <= 0, "%s: max |d|=%g at %s (ref %g)" % (
+        what, np.abs(got - ref).max(), np.unravel_index(np.argmax(err), err.shape), ref.flat[np.argmax(err)])
+
+
+# ---------------------------------------------------------------------------------------------------
+# environment + ring
+# ---------------------------------------------------------------------------------------------------
+def _run_env(ops, B, H, steps, actions, reset_on_terminal=True):
+    """Drive the device env and B oracle envs + oracle replays with the same actions."""
+    ring = ops.Ring(B, H, DEV)
+    ops.maze_reset(ring)
+    envs = [OM.OracleMaze() for _ in range(B)]
+    exps = [OracleExperience(H) for _ in range(B)]
+    out_r = torch.zeros(B, device=DEV)
+    out_t = torch.zeros(B, dtype=torch.int32, device=DEV)
+    for s in range(steps):
+        a = actions[s]
+        ops.maze_step(ring, dev(a, torch.int32), None, out_r, out_t, reset_on_terminal, True)
+        rr, tt = out_r.cpu().numpy(), out_t.cpu().numpy()
+        for b in range(B):
+            e = envs[b]
+            prev, la, lr = e.last_state, e.last_action, e.last_reward
+            _, r, t, pc = e.process(int(a[b]))
+            exps[b].add_frame(Frame(prev, r, int(a[b]), t, pc, la, lr))
+            assert rr[b] == r and bool(tt[b]) == bool(t)
+            if t and reset_on_terminal:
+                e.reset()
+    return ring, envs, exps
+
+
+def _check_ring(ring, envs, exps):
+    B, H1 = ring.B, ring.H1
+    frames = ring.frames.cpu().numpy().reshape(B, H1, 84, 84, 3)
+    rr = ring.r_reward.cpu().numpy().reshape(B, H1)
+    ra = ring.r_action.cpu().numpy().reshape(B, H1)
+    rt = ring.r_terminal.cpu().numpy().reshape(B, H1)
+    rla = ring.r_last_action.cpu().numpy().reshape(B, H1)
+    rlr = ring.r_last_reward.cpu().numpy().reshape(B, H1)
+    rpc = ring.r_pc.cpu().numpy().reshape(B, H1, 20, 20)
+    cnt = ring.count.cpu().numpy()
+    pos = ring.pos.cpu().numpy().reshape(B, 2)
+    for b in range(B):
+        e, x = envs[b], exps[b]
+        assert cnt[b] == x.count
+        assert (pos[b, 0], pos[b, 1]) == (e.x, e.y)
+        # current observation is rendered in slot count % H1
+        np.testing.assert_array_equal(frames[b, cnt[b] % H1], e.last_state['image'].astype(np.uint8))
+        for i in range(x.top, x.count):
+            f = x.frames[i]
+            s = i % H1
+            np.testing.assert_array_equal(frames[b, s], f.state['image'].astype(np.uint8))
+            assert rr[b, s] == f.reward and ra[b, s] == f.action and bool(rt[b, s]) == bool(f.terminal)
+            assert rla[b, s] == f.last_action and rlr[b, s] == f.last_reward
+            np.testing.assert_array_equal(rpc[b, s], f.pixel_change.astype(np.float32))   # bit-exact fp32
+    assert int(ring.last_action.cpu()[0]) == envs[0].last_action
+    assert float(ring.last_reward.cpu()[0]) == envs[0].last_reward
+
+
+def test_maze_step_random_walk_bit_exact(ops):
+    rs = np.random.RandomState(5)
+    B, H, steps = 6, 16, 120
+    actions = rs.randint(0, 4, size=(steps, B))
+    ring, envs, exps = _run_env(ops, B, H, steps, actions)
+    _check_ring(ring, envs, exps)
+
+
+def test_maze_golden_trace_and_episode(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "maze_trace.npz"))
+    n = 1500
+    B = 2
+    acts = np.stack([g["actions"][:n], g["actions"][:n][::-1]], 1)
+    ring = ops.Ring(B, 32, DEV)
+    ops.maze_reset(ring)
+    out_r = torch.zeros(B, device=DEV)
+    out_t = torch.zeros(B, dtype=torch.int32, device=DEV)
+    for i in range(n):
+        ops.maze_step(ring, dev(acts[i], torch.int32), None, out_r, out_t, True, False)
+        if i % 50 == 0 or g["terminal"][i]:
+            assert out_r.cpu()[0] == g["reward"][i] and bool(out_t.cpu()[0]) == bool(g["terminal"][i])
+            p = ring.pos.cpu().numpy()
+            exp_pos = tuple(g["pos"][i]) if not g["terminal"][i] else OM.START
+            assert (p[0], p[1]) == exp_pos
+    # scripted shortest path: 20 moves, return +1 (BASELINE.md derived fact)
+    from collections import deque
+    prev = {OM.START: None}
+    dq = deque([OM.START])
+    while dq:
+        c = dq.popleft()
+        for a in range(4):
+            nx, ny, _ = OM.move(c[0], c[1], a)
+            if (nx, ny) not in prev:
+                prev[(nx, ny)] = (c, a)
+                dq.append((nx, ny))
+    path = []
+    c = OM.GOAL
+    while prev[c] is not None:
+        c, a = prev[c]
+        path.append(a)
+    path.reverse()
+    assert len(path) == 20
+    ring = ops.Ring(1, 32, DEV)
+    ops.maze_reset(ring)
+    tot = 0.0
+    for a in path:
+        ops.maze_step(ring, dev([a], torch.int32), None, out_r[:1], out_t[:1], True, True)
+        tot += float(out_r.cpu()[0])
+    assert tot == 1.0 and int(out_t.cpu()[0]) == 1
+    assert float(ring.score_out.cpu()[0]) == 1.0 and int(ring.score_valid.cpu()[0]) == 1
+
+
+def test_maze_table_all_cells(ops, golden_dir):
+    """Every (free cell, action): next cell, reward, terminal, frame, pixel-change vs the reference table."""
+    g = np.load(os.path.join(golden_dir, "maze_table.npz"))
+    cells = g["cells"]
+    B = len(cells) * 4
+    ring = ops.Ring(B, 8, DEV)
+    ops.maze_reset(ring)
+    pos = np.repeat(cells, 4, axis=0).astype(np.int32)
+    ring.pos.copy_(dev(pos.reshape(-1)))
+    acts = np.tile(np.arange(4), len(cells)).astype(np.int32)
+    out_r = torch.zeros(B, device=DEV)
+    out_t = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.maze_step(ring, dev(acts), None, out_r, out_t, False, False)
+    np.testing.assert_array_equal(ring.pos.cpu().numpy().reshape(-1, 4, 2), g["next"])
+    np.testing.assert_array_equal(out_r.cpu().numpy().reshape(-1, 4), g["reward"].astype(np.float32))
+    np.testing.assert_array_equal(out_t.cpu().numpy().reshape(-1, 4), g["terminal"])
+    pc = ring.r_pc.cpu().numpy().reshape(B, 9, 20, 20)[:, 0].reshape(-1, 4, 20, 20)
+    np.testing.assert_array_equal(pc, g["pixel_change"].astype(np.float32))
+    fr = ring.frames.cpu().numpy().reshape(B, 9, 84, 84, 3)[:, 1]
+    cell_of = {tuple(c): i for i, c in enumerate(cells)}
+    for k in range(B):
+        np.testing.assert_array_equal(fr[k], g["frames"][cell_of[tuple(g["next"][k // 4, k % 4])]])
+    # generic uint8 pixel-change kernel agrees with the analytic maze form
+    before = np.stack([g["frames"][k // 4] for k in range(B)])
+    pool = torch.cat([dev(before.reshape(-1)), dev(fr.reshape(-1))])
+    idx_old = torch.arange(B, dtype=torch.int32, device=DEV)
+    idx_new = idx_old + B
+    out = torch.zeros(B * 400, device=DEV)
+    ops.pixel_change_u8(pool, idx_new, idx_old, 48.0, out)
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(-1, 4, 20, 20), g["pixel_change"].astype(np.float32))
+
+
+def test_replay_sampling_matches_oracle(ops):
+    rs = np.random.RandomState(11)
+    B, H, L = 8, 40, 11
+    steps = 150
+    actions = rs.randint(0, 4, size=(steps, B))
+    ring, envs, exps = _run_env(ops, B, H, steps, actions)
+    # inject terminals / rewards patterns that the random walk will not produce often
+    rt = ring.r_terminal.cpu().numpy().reshape(B, H + 1)
+    rr = ring.r_reward.cpu().numpy().reshape(B, H + 1)
+    for b in range(B):
+        x = exps[b]
+        for i in range(x.top, x.count):
+            if rs.rand() < 0.12:
+                x.frames[i].terminal = True
+                rt[b, i % (H + 1)] = 1
+            if rs.rand() < 0.2:
+                x.frames[i].reward = 1
+                rr[b, i % (H + 1)] = 1.0
+        # no successive terminals (the reference assumes so)
+        for i in range(x.top + 1, x.count):
+            if x.frames[i].terminal and x.frames[i - 1].terminal:
+                x.frames[i].terminal = False
+                rt[b, i % (H + 1)] = 0
+    ring.r_terminal.copy_(dev(rt.reshape(-1)))
+    ring.r_reward.copy_(dev(rr.reshape(-1)))
+    for trial in range(20):
+        start = rs.randint(0, H - L - 1, size=B).astype(np.int32)
+        seq_idx = torch.zeros(L * B, dtype=torch.int32, device=DEV)
+        seq_len = torch.zeros(B, dtype=torch.int32, device=DEV)
+        ops.replay_sample_seq(ring, L, dev(start), seq_idx, seq_len)
+        si = seq_idx.cpu().numpy().reshape(L, B)
+        sl = seq_len.cpu().numpy()
+        coin = rs.randint(0, 2, size=B).astype(np.int32)
+        u = rs.random_sample(B)
+        rp_idx = torch.zeros(3 * B, dtype=torch.int32, device=DEV)
+        rp_cls = torch.zeros(B, dtype=torch.int32, device=DEV)
+        ops.replay_sample_rp(ring, dev(coin), dev(u), rp_idx, rp_cls)
+        ri = rp_idx.cpu().numpy().reshape(B, 3)
+        rc = rp_cls.cpu().numpy()
+        for b in range(B):
+            x = exps[b]
+            want = x.sequence_from_start(int(start[b]), L)
+            assert sl[b] == len(want)
+            assert [b * (H + 1) + i % (H + 1) for i in want] == list(si[:len(want), b])
+            rp = x.rp_from_draws(int(coin[b]), lambda n: min(n - 1, int(u[b] * n)))
+            assert [b * (H + 1) + i % (H + 1) for i in rp[:3]] == list(ri[b])
+            r = x.frames[rp[3]].reward
+            assert rc[b] == (0 if r == 0 else (1 if r > 0 else 2))
+
+
+def test_return_scans(ops):
+    rs = np.random.RandomState(3)
+    B, T = 37, 20
+    rewards = rs.choice([-1.0, 0.0, 1.0], size=(T, B)).astype(np.float32)
+    values = rs.normal(size=(T, B)).astype(np.float32)
+    n_steps = rs.randint(1, T + 1, size=B).astype(np.int32)
+    n_steps[:5] = T
+    term_end = (n_steps < T).astype(np.int32)
+    boot = rs.normal(size=B).astype(np.float32)
+    R_out = torch.zeros(T * B, device=DEV)
+    adv_out = torch.zeros(T * B, device=DEV)
+    ops.base_returns(B, T, dev(rewards.reshape(-1)), dev(values.reshape(-1)), dev(n_steps), dev(boot),
+                     dev(term_end), 0.99, R_out, adv_out)
+    Rr = np.zeros((T, B), np.float32)
+    Ar = np.zeros((T, B), np.float32)
+    for b in range(B):
+        R = 0.0 if term_end[b] else float(boot[b])
+        for t in reversed(range(n_steps[b])):
+            R = float(rewards[t, b]) + 0.99 * R
+            Rr[t, b] = R
+            Ar[t, b] = R - float(values[t, b])
+    np.testing.assert_array_equal(R_out.cpu().numpy().reshape(T, B), Rr)
+    np.testing.assert_array_equal(adv_out.cpu().numpy().reshape(T, B), Ar)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb,M,N,K", [
+    (0, 0, 64, 256, 2592), (0, 0, 200, 1024, 261), (0, 0, 4096, 256, 512), (0, 0, 7, 5, 3),
+    (0, 1, 130, 2592, 256), (0, 1, 64, 256, 1024), (0, 1, 33, 261, 1024),
+    (1, 0, 2592, 256, 300), (1, 0, 261, 1024, 77), (1, 0, 256, 1024, 1000), (1, 1, 100, 70, 50),
+])
+def test_gemm_variants(ops, ta, tb, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    lda = ((M if ta else K) + 7) // 4 * 4
+    ldb = ((K if tb else N) + 7) // 4 * 4
+    ldc = N + 3
+    A = rs.uniform(-1, 1, size=((K if ta else M), lda))
+    B = rs.uniform(-1, 1, size=((N if tb else K), ldb))
+    bias = rs.uniform(-1, 1, size=N)
+    Aop = (A[:, :M].T if ta else A[:, :K])
+    Bop = (B[:, :K].T if tb else B[:, :N])
+    ref = Aop @ Bop
+    tol = dict(atol=3e-7 * K, rtol=1e-5)
+    C = torch.full((M, ldc), 7.0, device=DEV)
+    ops.gemm(ta, tb, M, N, K, dev(A, torch.float32), lda, dev(B, torch.float32), ldb, C, ldc, bias=dev(bias, torch.float32))
+    close(C[:, :N], ref + bias, what="bias", **tol)
+    assert float(C[:, N:].min()) == 7.0                      # padding columns untouched
+    # relu + accumulate
+    C0 = rs.uniform(-1, 1, size=(M, ldc))
+    C = dev(C0, torch.float32)
+    ops.gemm(ta, tb, M, N, K, dev(A, torch.float32), lda, dev(B, torch.float32), ldb, C, ldc,
+             flags=ops.GEMM_ACCUM | ops.GEMM_RELU)
+    close(C[:, :N], np.maximum(ref + C0[:, :N], 0), what="accum+relu", **tol)
+    # relu mask
+    msk = rs.uniform(-1, 1, size=(M, N))
+    C = torch.zeros(M, ldc, device=DEV)
+    ops.gemm(ta, tb, M, N, K, dev(A, torch.float32), lda, dev(B, torch.float32), ldb, C, ldc,
+             mask=dev(msk, torch.float32), ldm=N, flags=ops.GEMM_RELU_MASK)
+    close(C[:, :N], ref * (msk > 0), what="mask", **tol)
+    # split-K atomics
+    C = torch.zeros(M, ldc, device=DEV)
+    ops.gemm(ta, tb, M, N, K, dev(A, torch.float32), lda, dev(B, torch.float32), ldb, C, ldc,
+             bias=dev(bias, torch.float32), flags=ops.GEMM_ATOMIC, splitk=4)
+    close(C[:, :N], ref + bias, what="splitk", **tol)
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    n = 96
+    Bm = np.arange(n * n, dtype=np.float32).reshape(n, n) % 251
+    C = torch.zeros(n, n, device=DEV)
+    ops.gemm(0, 0, n, n, n, dev(np.eye(n, dtype=np.float32)), n, dev(Bm), n, C, n)
+    np.testing.assert_array_equal(C.cpu().numpy(), Bm)
+
+
+# ---------------------------------------------------------------------------------------------------
+# encoder
+# ---------------------------------------------------------------------------------------------------
+def _enc_params(seed):
+    p = M.init_params(4, seed=seed, dtype=torch.float64)
+    rs = np.random.RandomState(seed)
+    p["b_base_conv1"] = torch.tensor(rs.uniform(-.05, .05, 16))
+    return p
+
+
+@pytest.mark.parametrize("N,mode", [(1, "maze"), (5, "u8"), (67, "u8"), (600, "maze")])
+def test_encoder_fwd(ops, N, mode):
+    rs = np.random.RandomState(N)
+    p = _enc_params(1)
+    pool_n = N + 3
+    if mode == "maze":
+        pool = rs.randint(0, 2, size=(pool_n, 84, 84, 3)).astype(np.uint8)
+        scale = 1.0
+    else:
+        pool = rs.randint(0, 256, size=(pool_n, 84, 84, 3)).astype(np.uint8)
+        scale = 1.0 / 255.0
+    idx = rs.randint(0, pool_n, size=N).astype(np.int32)
+    x = torch.tensor(pool[idx].astype(np.float64)) * scale
+    h1, h2 = M.encoder(x, p)
+    f2 = torch.zeros(N * 2592, device=DEV)
+    c1 = torch.zeros(N * 6400, device=DEV)
+    P = {k: dev(v, torch.float32) for k, v in p.items()}
+    ops.encoder_fwd(dev(pool.reshape(-1)), dev(idx), scale, P["W_base_conv1"], P["b_base_conv1"],
+                    P["W_base_conv2"], P["b_base_conv2"], f2, c1)
+    close(c1.reshape(N, 20, 20, 16), h1, what="conv1")
+    close(f2.reshape(N, 9, 9, 32), h2, what="conv2")
+    f2b = torch.zeros(N * 2592, device=DEV)
+    ops.encoder_fwd(dev(pool.reshape(-1)), dev(idx), scale, P["W_base_conv1"], P["b_base_conv1"],
+                    P["W_base_conv2"], P["b_base_conv2"], f2b, None)
+    assert torch.equal(f2, f2b)
+
+
+@pytest.mark.parametrize("N", [1, 6, 131])
+def test_encoder_bwd(ops, N):
+    rs = np.random.RandomState(N + 100)
+    p = _enc_params(2)
+    pool = rs.randint(0, 256, size=(N, 84, 84, 3)).astype(np.uint8)
+    scale = 1.0 / 255.0
+    idx = rs.permutation(N).astype(np.int32)
+    W1 = p["W_base_conv1"].clone().requires_grad_(True)
+    b1 = p["b_base_conv1"].clone().requires_grad_(True)
+    W2 = p["W_base_conv2"].clone().requires_grad_(True)
+    b2 = p["b_base_conv2"].clone().requires_grad_(True)
+    q = dict(W_base_conv1=W1, b_base_conv1=b1, W_base_conv2=W2, b_base_conv2=b2)
+    x = torch.tensor(pool[idx].astype(np.float64)) * scale
+    h1, h2 = M.encoder(x, q)
+    g_out = torch.tensor(rs.normal(size=h2.shape))
+    (h2 * g_out).sum().backward()
+    d2 = (g_out * (h2 > 0)).detach()          # gradient wrt conv2 pre-activation
+    P = {k: dev(v, torch.float32) for k, v in p.items()}
+    dW1 = torch.zeros(3072, device=DEV); db1 = torch.zeros(16, device=DEV)
+    dW2 = torch.zeros(8192, device=DEV); db2 = torch.zeros(32, device=DEV)
+    ops.encoder_bwd(dev(pool.reshape(-1)), dev(idx), scale, P["W_base_conv2"],
+                    dev(h1.detach().reshape(-1), torch.float32), dev(d2.reshape(-1), torch.float32),
+                    dW1, db1, dW2, db2)
+    tol = dict(atol=3e-5 * max(1, N ** 0.5), rtol=1e-4)
+    close(dW2.reshape(4, 4, 16, 32), W2.grad, what="dW2", **tol)
+    close(db2, b2.grad, what="db2", **tol)
+    close(db1, b1.grad, what="db1", **tol)
+    close(dW1.reshape(8, 8, 3, 16), W1.grad, what="dW1", **tol)
+
+
+# ---------------------------------------------------------------------------------------------------
+# LSTM gates, heads, losses
+# ---------------------------------------------------------------------------------------------------
+def test_lstm_gates_fwd_bwd(ops):
+    rs = np.random.RandomState(9)
+    rows = 70
+    pre = torch.tensor(rs.normal(size=(rows, 1024)), requires_grad=True)
+    bias = torch.tensor(rs.normal(size=1024) * 0.1, requires_grad=True)
+    c0 = torch.tensor(rs.normal(size=(rows, 256)), requires_grad=True)
+    g = pre + bias
+    i, j, f, o = torch.sigmoid(g[:, :256]), torch.tanh(g[:, 256:512]), torch.sigmoid(g[:, 512:768] + 1.0), \
+        torch.sigmoid(g[:, 768:])
+    c = c0 * f + i * j
+    h = torch.tanh(c) * o
+    dh = torch.tensor(rs.normal(size=(rows, 256)))
+    dhr = torch.tensor(rs.normal(size=(rows, 256)))
+    dc = torch.tensor(rs.normal(size=(rows, 256)))
+    ((h * (dh + dhr)).sum() + (c * dc).sum()).backward()
+    ga = torch.zeros(rows * 1024, device=DEV); co = torch.zeros(rows * 256, device=DEV)
+    ho = torch.zeros(rows * 264, device=DEV)
+    ops.lstm_gates_fwd(rows, dev(pre.detach().reshape(-1), torch.float32), dev(bias.detach(), torch.float32),
+                       dev(c0.detach().reshape(-1), torch.float32), ga, co, ho, 264)
+    close(co.reshape(rows, 256), c, what="c")
+    close(ho.reshape(rows, 264)[:, :256], h, what="h")
+    close(ga.reshape(rows, 1024), torch.cat([i, j, f, o], 1), what="gates")
+    dpre = torch.zeros(rows * 1024, device=DEV)
+    dcio = dev(dc.reshape(-1), torch.float32)
+    ops.lstm_gates_bwd(rows, dev(dh.reshape(-1), torch.float32), dev(dhr.reshape(-1), torch.float32), dcio, ga,
+                       dev(c0.detach().reshape(-1), torch.float32), co, dpre)
+    close(dpre.reshape(rows, 1024), pre.grad, what="dpre", atol=5e-5, rtol=1e-4)
+    close(dcio.reshape(rows, 256), c0.grad, what="dc_prev", atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("rows,K,NOUT", [(37, 256, 4), (37, 256, 1), (300, 7776, 3), (5, 256, 6)])
+def test_linear_small(ops, rows, K, NOUT):
+    rs = np.random.RandomState(rows + K)
+    ldx = K + 8
+    X = torch.tensor(rs.normal(size=(rows, ldx)), requires_grad=True)
+    W = torch.tensor(rs.normal(size=(K, NOUT)) / np.sqrt(K), requires_grad=True)
+    b = torch.tensor(rs.normal(size=NOUT), requires_grad=True)
+    out = X[:, :K] @ W + b
+    dO = torch.tensor(rs.normal(size=(rows, NOUT)))
+    (out * dO).sum().backward()
+    o = torch.zeros(rows * NOUT, device=DEV)
+    ops.linear_small_fwd(rows, K, NOUT, dev(X.detach().reshape(-1), torch.float32), ldx,
+                         dev(W.detach().reshape(-1), torch.float32), dev(b.detach(), torch.float32), o, NOUT)
+    close(o.reshape(rows, NOUT), out, what="fwd", atol=1e-4, rtol=1e-4)
+    dX0 = rs.normal(size=(rows, K))
+    dX = dev(dX0.reshape(-1), torch.float32)
+    dW = torch.zeros(K * NOUT, device=DEV); db = torch.zeros(NOUT, device=DEV)
+    ops.linear_small_bwd(rows, K, NOUT, dev(X.detach().reshape(-1), torch.float32), ldx,
+                         dev(dO.reshape(-1), torch.float32), NOUT, dev(W.detach().reshape(-1), torch.float32), dX, K,
+                         True, dW, db)
+    close(dX.reshape(rows, K), X.grad[:, :K] + dX0, what="dX", atol=1e-4, rtol=1e-4)
+    close(dW.reshape(K, NOUT), W.grad, what="dW", atol=2e-4, rtol=1e-4)
+    close(db, b.grad, what="db", atol=2e-4, rtol=1e-4)
+
+
+def test_softmax_sample_matches_numpy_choice(ops):
+    rs = np.random.RandomState(4)
+    rows, A = 4096, 4
+    logits = (rs.normal(size=(rows, A)) * 3).astype(np.float32)
+    u = rs.random_sample(rows)
+    u[:8] = [0.0, 1.0 - 2 ** -53, 0.25, 0.5, 0.75, 0.1, 0.9, 0.999999]
+    lp = dev(logits.reshape(-1))
+    act = torch.zeros(rows, dtype=torch.int32, device=DEV)
+    ops.softmax_sample(rows, A, lp, A, dev(u), act)
+    pi = lp.cpu().numpy().reshape(rows, A)
+    ref = torch.softmax(torch.tensor(logits.astype(np.float64)), 1).numpy()
+    close(pi, ref, atol=1e-6, rtol=1e-5, what="pi")
+    # inverse-CDF draw exactly as numpy RandomState.choice does it (trainer.py:147-148), on the device's own pi
+    cdf = np.cumsum(pi.astype(np.float64), 1)
+    cdf /= cdf[:, -1:]
+    want = np.array([np.searchsorted(cdf[r], u[r], side='right') for r in range(rows)])
+    np.testing.assert_array_equal(act.cpu().numpy(), np.minimum(want, A - 1))
+
+
+def test_base_vr_rp_loss_grads(ops):
+    rs = np.random.RandomState(8)
+    rows, A = 333, 4
+    beta, gs = 0.001, 1.0 / 7
+    logits = torch.tensor(rs.normal(size=(rows, A)) * 2, requires_grad=True)
+    v = torch.tensor(rs.normal(size=rows), requires_grad=True)
+    act = rs.randint(0, A, rows)
+    adv = torch.tensor(rs.normal(size=rows)); R = torch.tensor(rs.normal(size=rows))
+    active = (rs.rand(rows) < 0.8).astype(np.int32)
+    m = torch.tensor(active.astype(np.float64))
+    pi = torch.softmax(logits, 1)
+    a1h = torch.tensor(np.eye(A)[act])
+    log_pi = torch.log(torch.clamp(pi, 1e-20, 1.0))
+    ent = -(pi * log_pi).sum(1)
+    pl = -(((log_pi * a1h).sum(1) * adv + ent * beta) * m).sum()
+    vl = 0.25 * (((R - v) ** 2) * m).sum()
+    ((pl + vl) * gs).backward()
+    dl = torch.zeros(rows * A, device=DEV); dv = torch.zeros(rows, device=DEV); losses = torch.zeros(3, device=DEV)
+    ops.base_loss_grad(rows, A, dev(pi.detach().reshape(-1), torch.float32), A, dev(v.detach(), torch.float32),
+                       dev(act, torch.int32), dev(adv, torch.float32), dev(R, torch.float32), dev(active), beta, gs,
+                       dl, dv, losses)
+    close(dl.reshape(rows, A), logits.grad, what="dlogits", atol=1e-6, rtol=1e-4)
+    close(dv, v.grad, what="dv", atol=1e-6, rtol=1e-4)
+    close(losses, [float(pl) * gs, float(vl) * gs, float((ent * m).sum()) * gs], atol=1e-4, rtol=1e-4, what="losses")
+    # value replay
+    v2 = torch.tensor(rs.normal(size=rows), requires_grad=True)
+    l2 = 0.5 * (((R - v2) ** 2) * m).sum()
+    (l2 * gs).backward()
+    dv2 = torch.zeros(rows, device=DEV); ls = torch.zeros(1, device=DEV)
+    ops.vr_loss_grad(rows, dev(v2.detach(), torch.float32), dev(R, torch.float32), dev(active), gs, dv2, ls)
+    close(dv2, v2.grad, what="vr dv", atol=1e-6, rtol=1e-4)
+    close(ls, [float(l2) * gs], atol=1e-4, rtol=1e-4, what="vr loss")
+    # reward prediction
+    z = torch.tensor(rs.normal(size=(rows, 3)) * 2, requires_grad=True)
+    cls = rs.randint(0, 3, rows)
+    pr = torch.softmax(z, 1)
+    l3 = -(torch.tensor(np.eye(3)[cls]) * torch.log(torch.clamp(pr, 1e-20, 1.0))).sum()
+    (l3 * gs).backward()
+    prob = torch.zeros(rows * 3, device=DEV); dz = torch.zeros(rows * 3, device=DEV); ls = torch.zeros(1, device=DEV)
+    ops.rp_loss_grad(rows, dev(z.detach().reshape(-1), torch.float32), dev(cls, torch.int32), gs, prob, dz, ls)
+    close(prob.reshape(rows, 3), pr, atol=1e-6, rtol=1e-5, what="rp prob")
+    close(dz.reshape(rows, 3), z.grad, atol=1e-6, rtol=1e-4, what="rp dlogits")
+    close(ls, [float(l3) * gs], atol=1e-4, rtol=1e-4, what="rp loss")
+
+
+def test_colsum_relu_mask_lar(ops):
+    rs = np.random.RandomState(2)
+    rows, cols, ld = 777, 300, 304
+    X = rs.normal(size=(rows, ld)).astype(np.float32)
+    out = torch.zeros(cols, device=DEV)
+    ops.colsum(rows, cols, dev(X.reshape(-1)), ld, out)
+    close(out, X[:, :cols].astype(np.float64).sum(0), atol=1e-3, rtol=1e-5, what="colsum")
+    S = rs.normal(size=(rows, cols)).astype(np.float32)
+    D = dev(X.reshape(-1).copy())
+    ops.relu_mask(rows, cols, D, ld, dev(S.reshape(-1)), cols)
+    want = X.copy()
+    want[:, :cols] *= (S > 0)
+    np.testing.assert_array_equal(D.cpu().numpy().reshape(rows, ld), want)
+    la = rs.randint(0, 4, 50).astype(np.int32); lr = rs.choice([-1.0, 0.0, 1.0], 50).astype(np.float32)
+    idx = rs.randint(0, 50, 20).astype(np.int32)
+    xc = torch.full((20 * 264,), 9.0, device=DEV)
+    ops.lar_fill(20, 4, dev(la), dev(lr), dev(idx), xc, 264)
+    got = xc.cpu().numpy().reshape(20, 264)
+    assert (got[:, :256] == 9.0).all() and (got[:, 261:] == 0).all()
+    for r in range(20):
+        from oracle.experience import concat_action_and_reward
+        np.testing.assert_array_equal(got[r, 256:261], concat_action_and_reward(la[idx[r]], 4, lr[idx[r]]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# pixel-control head
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,A", [(1, 4), (9, 4), (130, 4), (7, 6), (5, 3)])
+def test_pc_deconv_fwd_bwd(ops, N, A):
+    rs = np.random.RandomState(N * 10 + A)
+    lam, gs = 0.05, 0.25
+    hp = torch.tensor(np.maximum(rs.normal(size=(N, 9, 9, 32)), 0), requires_grad=True)
+    Wv = torch.tensor(rs.uniform(-.1, .1, (4, 4, 1, 32)), requires_grad=True)
+    bv = torch.tensor(rs.uniform(-.1, .1, 1), requires_grad=True)
+    Wa = torch.tensor(rs.uniform(-.1, .1, (4, 4, A, 32)), requires_grad=True)
+    ba = torch.tensor(rs.uniform(-.1, .1, A), requires_grad=True)
+    x = hp.permute(0, 3, 1, 2)
+    v = F.relu(F.conv_transpose2d(x, Wv.permute(3, 2, 0, 1), bv, stride=2))
+    a = F.relu(F.conv_transpose2d(x, Wa.permute(3, 2, 0, 1), ba, stride=2))
+    q = (v + a - a.mean(1, keepdim=True)).permute(0, 2, 3, 1)
+    qmax_ref = q.max(3)[0]
+    act = rs.randint(0, A, N)
+    tgt = torch.tensor(rs.uniform(0, 1, (N, 20, 20)))
+    mask = (rs.rand(N) < 0.8).astype(np.int32)
+    mask[0] = 1
+    m = torch.tensor(mask.astype(np.float64)).reshape(N, 1, 1)
+    qa = (q * torch.tensor(np.eye(A)[act]).reshape(N, 1, 1, A)).sum(3)
+    loss = lam * 0.5 * (((tgt - qa) ** 2) * m).sum()
+    (loss * gs).backward()
+    f32 = torch.float32
+    d = dict(hp=dev(hp.detach().reshape(-1), f32), Wv=dev(Wv.detach().reshape(-1), f32), bv=dev(bv.detach(), f32),
+             Wa=dev(Wa.detach().reshape(-1), f32), ba=dev(ba.detach(), f32))
+    qmax = torch.zeros(N * 400, device=DEV)
+    ops.pc_deconv_fwd(N, A, d["hp"], d["Wv"], d["bv"], d["Wa"], d["ba"], qmax=qmax)
+    close(qmax.reshape(N, 20, 20), qmax_ref, what="qmax")
+    d_dec = torch.zeros(N * 400 * (1 + A), device=DEV)
+    ls = torch.zeros(1, device=DEV)
+    ops.pc_deconv_fwd(N, A, d["hp"], d["Wv"], d["bv"], d["Wa"], d["ba"], action=dev(act, torch.int32),
+                      target=dev(tgt.reshape(-1), f32), mask=dev(mask), lam=lam, grad_scale=gs, d_dec=d_dec, loss=ls)
+    close(ls, [float(loss) * gs], atol=1e-4, rtol=1e-4, what="pc loss")
+    d_hp = torch.zeros(N * 2592, device=DEV)
+    dWv = torch.zeros(512, device=DEV); dbv = torch.zeros(1, device=DEV)
+    dWa = torch.zeros(512 * A, device=DEV); dba = torch.zeros(A, device=DEV)
+    ops.pc_deconv_bwd(N, A, d["hp"], d_dec, d["Wv"], d["Wa"], d_hp, dWv, dbv, dWa, dba)
+    tol = dict(atol=2e-5, rtol=1e-4)
+    close(d_hp.reshape(N, 9, 9, 32), hp.grad * (hp.detach() > 0), what="d_hp", **tol)
+    close(dWv.reshape(4, 4, 1, 32), Wv.grad, what="dWv", **tol)
+    close(dWa.reshape(4, 4, A, 32), Wa.grad, what="dWa", **tol)
+    close(dbv, bv.grad, what="dbv", **tol)
+    close(dba, ba.grad, what="dba", **tol)
+
+
+def test_pc_vr_return_scans(ops):
+    rs = np.random.RandomState(21)
+    B, H, L = 5, 40, 21
+    ring, envs, exps = _run_env(ops, B, H, 90, rs.randint(0, 4, size=(90, B)))
+    rt = ring.r_terminal.cpu().numpy().reshape(B, H + 1)
+    for b in range(B):
+        x = exps[b]
+        for i in range(x.top, x.count, 7 + b):
+            x.frames[i].terminal = True
+            rt[b, i % (H + 1)] = 1
+    ring.r_terminal.copy_(dev(rt.reshape(-1)))
+    start = rs.randint(0, H - L - 1, size=B).astype(np.int32)
+    seq_idx = torch.zeros(L * B, dtype=torch.int32, device=DEV)
+    seq_len = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.replay_sample_seq(ring, L, dev(start), seq_idx, seq_len)
+    qmax = rs.uniform(0, 1, size=(B, 400)).astype(np.float32)
+    bv = rs.normal(size=B).astype(np.float32)
+    pcR = torch.zeros((L - 1) * B * 400, device=DEV)
+    vrR = torch.zeros((L - 1) * B, device=DEV)
+    ops.pc_returns(ring, L, seq_idx, seq_len, dev(qmax.reshape(-1)), 0.9, pcR)
+    ops.vr_returns(ring, L, seq_idx, seq_len, dev(bv), 0.99, vrR)
+    msk = torch.zeros((L - 1) * B, dtype=torch.int32, device=DEV)
+    ops.seq_mask(B, L - 1, seq_len, msk)
+    pcR = pcR.cpu().numpy().reshape(L - 1, B, 20, 20); vrR = vrR.cpu().numpy().reshape(L - 1, B)
+    msk = msk.cpu().numpy().reshape(L - 1, B)
+    for b in range(B):
+        x = exps[b]
+        fr = [x.frames[i] for i in x.sequence_from_start(int(start[b]), L)]
+        rev = fr[::-1]
+        pc_R = np.zeros((20, 20), np.float32) if rev[1].terminal else qmax[b].reshape(20, 20)
+        vr_R = 0.0 if rev[1].terminal else float(bv[b])
+        pcs, vrs = [], []
+        for f in rev[1:]:
+            pc_R = f.pixel_change + 0.9 * pc_R
+            vr_R = f.reward + 0.99 * vr_R
+            pcs.append(pc_R); vrs.append(vr_R)
+        pcs.reverse(); vrs.reverse()
+        n = len(fr)
+        assert list(msk[:, b]) == [1] * (n - 1) + [0] * (L - n)
+        # the reference mixes float32 (Q-max, first product) and float64 here; the kernel scans in fp64
+        close(pcR[:n - 1, b], np.asarray(pcs), atol=1e-7, rtol=1e-6, what="pc_R")
+        np.testing.assert_array_equal(vrR[:n - 1, b], np.asarray(vrs, dtype=np.float32))
+        assert (pcR[n - 1:, b] == 0).all() and (vrR[n - 1:, b] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# optimiser, RNG
+# ---------------------------------------------------------------------------------------------------
+def test_rmsprop_known_answer_and_oracle(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rmsprop_known_answer.npz"))
+    var = torch.zeros(4, device=DEV); var[:2] = dev(g["var0"], torch.float32)
+    ms = torch.ones(4, device=DEV); mom = torch.zeros(4, device=DEV)
+    for k in range(2):
+        gr = torch.zeros(4, device=DEV); gr[:2] = dev(g["grads"][k], torch.float32)
+        ops.rmsprop_step(var, ms, mom, gr, 2.0, 0.9, 0.0, 1.0, 0.0, None)
+        close(var[:2], g["steps"][k, :2], atol=0, rtol=1e-6, what="known answer step %d" % k)
+    rs = np.random.RandomState(0)
+    n = 1898877
+    p0 = rs.normal(size=n).astype(np.float32)
+    var = dev(p0.copy()); ms = torch.ones(n, device=DEV); mom = torch.zeros(n, device=DEV)
+    orc = OracleRMSProp(decay=0.99, momentum=0.0, epsilon=0.1, clip_norm=40.0)
+    pl = [p0.copy()]
+    scratch = torch.zeros(256, device=DEV); norm = torch.zeros(1, device=DEV)
+    for k, scale in enumerate((0.5, 0.001)):       # first step clips (norm ~ 689), second does not (~1.4)
+        gr = (rs.normal(size=n) * scale).astype(np.float32)
+        gd = dev(gr)
+        ops.grad_norm(gd, scratch, norm)
+        ops.rmsprop_step(var, ms, mom, gd, 7e-4, 0.99, 0.0, 0.1, 40.0, norm)
+        nr = orc.step(pl, [gr], 7e-4)
+        close(norm, [np.sqrt((gr.astype(np.float64) ** 2).sum())], atol=0, rtol=2e-6, what="norm")
+        close(var, pl[0], atol=1e-7, rtol=1e-6, what="var step %d" % k)
+        close(ms, orc.ms[0], atol=1e-7, rtol=1e-6, what="ms")
+
+
+def test_philox(ops):
+    n = 100000
+    a = torch.zeros(n, dtype=torch.float64, device=DEV); b = torch.zeros(n, dtype=torch.float64, device=DEV)
+    ops.philox_uniform(0xA3C, 1, a); ops.philox_uniform(0xA3C, 1, b)
+    assert torch.equal(a, b)
+    ops.philox_uniform(0xA3C, 2, b)
+    assert not torch.equal(a, b)
+    x = a.cpu().numpy()
+    assert 0.0 <= x.min() and x.max() < 1.0 and abs(x.mean() - 0.5) < 0.005 and abs(x.var() - 1 / 12) < 0.002
+    r = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ops.philox_randint(7, 3, 1978, r)
+    y = r.cpu().numpy()
+    assert y.min() >= 0 and y.max() <= 1977 and abs(y.mean() - 988.5) < 8
+    # Philox4x32-10 known-answer (Random123 kat_vectors: counter = key = 0 -> 6627e8d5 e169c58d ...)
+    ops.philox_uniform(0, 0, a[:1])
+    want = ((0x6627e8d5 >> 5) * 67108864.0 + (0xe169c58d >> 6)) / 9007199254740992.0
+    assert float(a.cpu()[0]) == want

@@ -1,0 +1,294 @@
+// Batched maze environment (K1), pixel change (K2) and the replay-ring write, for gfx950.
+//
+// Reference behaviour restated (never copied) from
+//   /root/reference/environment/maze_environment.py:18-128  (map, _move, _get_current_image, process)
+//   /root/reference/environment/environment.py:88-102       (_calc_pixel_change)
+//   /root/reference/train/experience.py:63-93                (add_frame; successive-terminal discard)
+//   /root/reference/train/trainer.py:194-205,264-296         (who resets what, and when)
+//
+// Layout: every actor owns H1 = history_size + 1 physical ring slots.  The observation the policy
+// is about to act on already lives in slot (count % H1) -- the env renders s_{t+1} straight into
+// the slot that the NEXT add_frame will commit, so a frame is written to HBM exactly once and is
+// never copied.  The extra slot keeps the oldest committed frame intact while it is still
+// sample-able.  One workgroup (256 threads) per actor: 21,168 B of frame are written with
+// 16 B/lane coalesced stores; the kernel is a pure HBM-write stream.
+#include "common.h"
+
+namespace {
+
+constexpr const char* kMap =
+    "--+---G"
+    "--+-+++"
+    "S-+---+"
+    "--+++--"
+    "--+-+--"
+    "--+----"
+    "-----++";
+
+constexpr uint64_t wall_mask() {
+  uint64_t m = 0;
+  for (int i = 0; i < 49; ++i)
+    if (kMap[i] == '+') m |= (1ull << i);
+  return m;
+}
+constexpr int find_cell(char c) {
+  for (int i = 0; i < 49; ++i)
+    if (kMap[i] == c) return i;
+  return -1;
+}
+constexpr uint64_t kWalls = wall_mask();
+constexpr int kStartX = find_cell('S') % 7, kStartY = find_cell('S') / 7;
+constexpr int kGoalX = find_cell('G') % 7, kGoalY = find_cell('G') / 7;
+static_assert(kStartX == 0 && kStartY == 2 && kGoalX == 6 && kGoalY == 0, "maze constants");
+
+__device__ __forceinline__ bool is_wall(int x, int y) { return (kWalls >> (y * 7 + x)) & 1ull; }
+
+// one byte of the rendered frame: ch0 = wall block, ch1 = agent block, ch2 = 0
+__device__ __forceinline__ uint32_t render_byte(int idx, int ax, int ay) {
+  int row = idx / FRAME_ROW_BYTES;
+  int c3 = idx - row * FRAME_ROW_BYTES;
+  int col = c3 / 3;
+  int ch = c3 - col * 3;
+  int cy = row / 12, cx = col / 12;
+  uint32_t wall = (uint32_t)((kWalls >> (cy * 7 + cx)) & 1ull);
+  uint32_t agent = (cx == ax && cy == ay) ? 1u : 0u;
+  return ch == 0 ? wall : (ch == 1 ? agent : 0u);
+}
+
+__device__ __forceinline__ void render_frame(uint8_t* dst, int ax, int ay) {
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int base = c * 16 + k * 4;
+      w[k] = render_byte(base, ax, ay) | (render_byte(base + 1, ax, ay) << 8) |
+             (render_byte(base + 2, ax, ay) << 16) | (render_byte(base + 3, ax, ay) << 24);
+    }
+    d4[c] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// pixels of the 12x12 agent block at cell (cx,cy) inside pixel-change cell (i,j):
+// rows 4i+2..4i+5, cols 4j+2..4j+5 of the full frame (the [2:-2] crop, then 4x4 blocks)
+__device__ __forceinline__ int overlap1(int cell, int k) {
+  int lo = max(12 * cell, 4 * k + 2), hi = min(12 * cell + 11, 4 * k + 5);
+  return max(0, hi - lo + 1);
+}
+
+struct StepArgs {
+  int B, H1;
+  const int* actions;
+  const int* active;
+  int* pos;
+  int* last_action;
+  float* last_reward;
+  int* count;
+  uint8_t* frames;
+  float* r_reward;
+  int* r_action;
+  int* r_terminal;
+  int* r_last_action;
+  float* r_last_reward;
+  float* r_pc;
+  float* out_reward;
+  int* out_terminal;
+  float* episode_reward;
+  float* score_out;
+  int* score_valid;
+  int reset_on_terminal;
+  int track_score;
+};
+
+__global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
+  const int b = blockIdx.x;
+  if (p.active && !p.active[b]) return;
+  const int H1 = p.H1;
+  const int x = p.pos[2 * b], y = p.pos[2 * b + 1];
+  const int a = p.actions[b];
+  const int cnt = p.count[b];
+  const int la = p.last_action[b];
+  const float lr = p.last_reward[b];
+  const int slot = cnt % H1;
+  const int prev_term = cnt > 0 ? p.r_terminal[(size_t)b * H1 + (cnt - 1) % H1] : 0;
+  float ep = p.track_score ? p.episode_reward[b] : 0.f;
+
+  // _move (maze_environment.py:76-91)
+  int dx = (a == 3) - (a == 2), dy = (a == 1) - (a == 0);
+  int nx = x + dx, ny = y + dy;
+  bool clamped = nx < 0 || nx > 6 || ny < 0 || ny > 6;
+  nx = min(max(nx, 0), 6);
+  ny = min(max(ny, 0), 6);
+  bool hit_wall = is_wall(nx, ny);
+  if (hit_wall) { nx = x; ny = y; }
+  const bool hit = clamped || hit_wall;
+  const bool terminal = (nx == kGoalX && ny == kGoalY);
+  const float reward = terminal ? 1.f : (hit ? -1.f : 0.f);
+  __syncthreads();  // every thread has read the actor's state before anyone overwrites it
+
+  const size_t base = (size_t)b * H1 + slot;
+  // pixel change between render(nx,ny) and render(x,y): only the two agent blocks differ (ch 1)
+  const bool moved = (nx != x) || (ny != y);
+  for (int c = threadIdx.x; c < PC_CELLS; c += blockDim.x) {
+    int i = c / 20, j = c - i * 20;
+    int s = 0;
+    if (moved) s = overlap1(y, i) * overlap1(x, j) + overlap1(ny, i) * overlap1(nx, j);
+    p.r_pc[base * PC_CELLS + c] = (float)s / 48.0f;
+  }
+
+  const bool discard = terminal && cnt > 0 && prev_term;  // experience.py:64-67
+  const int ncnt = discard ? cnt : cnt + 1;
+  const bool reset = terminal && p.reset_on_terminal;
+  const int rx = reset ? kStartX : nx, ry = reset ? kStartY : ny;
+  const int nslot = ncnt % H1;
+  render_frame(p.frames + ((size_t)b * H1 + nslot) * FRAME_BYTES, rx, ry);
+
+  if (threadIdx.x == 0) {
+    p.r_reward[base] = reward;
+    p.r_action[base] = a;
+    p.r_terminal[base] = terminal ? 1 : 0;
+    p.r_last_action[base] = la;
+    p.r_last_reward[base] = lr;
+    p.pos[2 * b] = rx;
+    p.pos[2 * b + 1] = ry;
+    p.count[b] = ncnt;
+    p.last_action[b] = reset ? 0 : a;
+    p.last_reward[b] = reset ? 0.f : reward;
+    if (p.out_reward) p.out_reward[b] = reward;
+    if (p.out_terminal) p.out_terminal[b] = terminal ? 1 : 0;
+    if (p.track_score) {
+      ep += reward;
+      if (terminal) {
+        p.score_out[b] = ep;
+        p.score_valid[b] = 1;
+        ep = 0.f;
+      }
+      p.episode_reward[b] = ep;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maze_reset_kernel(int B, int H1, const int* mask, int* pos,
+                                                         int* last_action, float* last_reward,
+                                                         const int* count, uint8_t* frames) {
+  const int b = blockIdx.x;
+  if (mask && !mask[b]) return;
+  const int slot = count[b] % H1;
+  render_frame(frames + ((size_t)b * H1 + slot) * FRAME_BYTES, kStartX, kStartY);
+  if (threadIdx.x == 0) {
+    pos[2 * b] = kStartX;
+    pos[2 * b + 1] = kStartY;
+    last_action[b] = 0;
+    last_reward[b] = 0.f;
+  }
+}
+
+// Generic pixel change between two stored uint8 frames (host-fed environments; also the
+// cross-check of the analytic maze form): out = sum_{4x4x3} |new - old| / denom.
+__global__ __launch_bounds__(256) void pixel_change_u8_kernel(int N, const uint8_t* frames,
+                                                              const int* idx_new, const int* idx_old,
+                                                              float denom, float* out) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * PC_CELLS) return;
+  int n = g / PC_CELLS, c = g - n * PC_CELLS;
+  int i = c / 20, j = c - i * 20;
+  const uint8_t* fa = frames + (size_t)idx_new[n] * FRAME_BYTES;
+  const uint8_t* fb = frames + (size_t)idx_old[n] * FRAME_BYTES;
+  int s = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int off = (4 * i + 2 + r) * FRAME_ROW_BYTES + (4 * j + 2) * 3;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s += abs((int)fa[off + k] - (int)fb[off + k]);
+  }
+  out[g] = (float)s / denom;
+}
+
+// ---- Philox4x32-10 counter RNG: key = seed, counter = (index, stream) ------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t index, uint64_t stream, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__global__ void philox_uniform_kernel(uint64_t seed, uint64_t stream, int n, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r[4];
+  philox4x32_10(seed, (uint64_t)i, stream, r);
+  // 53-bit uniform in [0,1), same construction as numpy's random_sample
+  out[i] = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
+}
+
+__global__ void philox_randint_kernel(uint64_t seed, uint64_t stream, int n, int high, int* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r[4];
+  philox4x32_10(seed, (uint64_t)i, stream, r);
+  out[i] = (int)(((uint64_t)r[0] * (uint64_t)high) >> 32);
+}
+
+}  // namespace
+
+extern "C" {
+
+int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* pos, int* last_action,
+                     float* last_reward, int* count, uint8_t* frames, float* r_reward, int* r_action,
+                     int* r_terminal, int* r_last_action, float* r_last_reward, float* r_pc,
+                     float* out_reward, int* out_terminal, float* episode_reward, float* score_out,
+                     int* score_valid, int reset_on_terminal, int track_score, void* stream) {
+  if (B <= 0 || H1 < 2 || !actions || !pos || !count || !frames) return UNREAL_EINVAL;
+  if (track_score && (!episode_reward || !score_out || !score_valid)) return UNREAL_EINVAL;
+  StepArgs p{B, H1, actions, active, pos, last_action, last_reward, count, frames, r_reward, r_action,
+             r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
+             score_out, score_valid, reset_on_terminal, track_score};
+  hipLaunchKernelGGL(maze_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+  return unreal_launch_status();
+}
+
+int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
+                      const int* count, uint8_t* frames, void* stream) {
+  if (B <= 0 || H1 < 2 || !pos || !count || !frames) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(maze_reset_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H1, mask, pos,
+                     last_action, last_reward, count, frames);
+  return unreal_launch_status();
+}
+
+int unreal_pixel_change_u8(int N, const uint8_t* frames, const int* idx_new, const int* idx_old,
+                           float denom, float* out, void* stream) {
+  if (N <= 0 || !frames || !idx_new || !idx_old || !out || denom <= 0.f) return UNREAL_EINVAL;
+  int total = N * PC_CELLS;
+  hipLaunchKernelGGL(pixel_change_u8_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     N, frames, idx_new, idx_old, denom, out);
+  return unreal_launch_status();
+}
+
+int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, double* out, void* stream) {
+  if (n <= 0 || !out) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(philox_uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
+                     stream_id, n, out);
+  return unreal_launch_status();
+}
+
+int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int high, int* out, void* stream) {
+  if (n <= 0 || high <= 0 || !out) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(philox_randint_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
+                     stream_id, n, high, out);
+  return unreal_launch_status();
+}
+
+}  // extern "C"

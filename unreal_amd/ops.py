@@ -1,0 +1,299 @@
+"""Host-side launch wrappers: torch tensors in, libunreal_hip.so kernels out.
+
+PyTorch is used for device memory and streams only; every computation below is a hand-written
+gfx950 kernel.  Each wrapper validates dtypes / sizes on the host before launching (a kernel that
+indexes out of bounds can take the whole GPU host down).
+"""
+import torch
+
+from ._lib import lib, ptr, stream
+
+FRAME_BYTES = 21168
+PC_CELLS = 400
+F2_DIM = 2592
+C1_DIM = 6400
+GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC, GEMM_RELU_MASK = 1, 2, 4, 8
+
+_DT = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64}
+
+
+def _chk(t, dt, n=None, name="tensor", optional=False):
+    if t is None:
+        if optional:
+            return
+        raise ValueError("%s is required" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP tensor (no CPU fallback)" % name)
+    if t.dtype != _DT[dt]:
+        raise ValueError("%s: dtype %s, expected %s" % (name, t.dtype, dt))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if n is not None and t.numel() < n:
+        raise ValueError("%s: %d elements, need >= %d" % (name, t.numel(), n))
+
+
+def _call(name, *a):
+    lib().call(name, *a, stream())
+
+
+# ---- environment ---------------------------------------------------------------------------------
+class Ring(object):
+    """Device replay ring + per-actor environment state (layout: include/unreal_hip.h)."""
+
+    def __init__(self, B, H, device):
+        self.B, self.H, self.H1 = B, H, H + 1
+        n = B * self.H1
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
+        self.frames = torch.empty(n * FRAME_BYTES, dtype=torch.uint8, device=device)
+        self.r_reward = z(n)
+        self.r_action = z(n, dt=torch.int32)
+        self.r_terminal = z(n, dt=torch.int32)
+        self.r_last_action = z(n, dt=torch.int32)
+        self.r_last_reward = z(n)
+        self.r_pc = torch.empty(n * PC_CELLS, dtype=torch.float32, device=device)
+        self.pos = z(B * 2, dt=torch.int32)
+        self.last_action = z(B, dt=torch.int32)
+        self.last_reward = z(B)
+        self.count = z(B, dt=torch.int32)
+        self.episode_reward = z(B)
+        self.score_out = z(B)
+        self.score_valid = z(B, dt=torch.int32)
+
+        self._cur = z(B, dt=torch.int32)
+
+    def cur_idx(self, out=None):
+        """Frame index of every actor's current observation (slot count % H1)."""
+        out = self._cur if out is None else out
+        _chk(out, "i32", self.B, "cur_idx out")
+        _call("unreal_ring_cur_idx", self.B, self.H1, ptr(self.count), ptr(out))
+        return out
+
+
+def maze_reset(ring, mask=None):
+    _chk(mask, "i32", ring.B, "mask", optional=True)
+    _call("unreal_maze_reset", ring.B, ring.H1, ptr(mask), ptr(ring.pos), ptr(ring.last_action),
+          ptr(ring.last_reward), ptr(ring.count), ptr(ring.frames))
+
+
+def maze_step(ring, actions, active=None, out_reward=None, out_terminal=None, reset_on_terminal=True,
+              track_score=False):
+    B = ring.B
+    _chk(actions, "i32", B, "actions")
+    _chk(active, "i32", B, "active", optional=True)
+    _chk(out_reward, "f32", B, "out_reward", optional=True)
+    _chk(out_terminal, "i32", B, "out_terminal", optional=True)
+    _call("unreal_maze_step", B, ring.H1, ptr(actions), ptr(active), ptr(ring.pos), ptr(ring.last_action),
+          ptr(ring.last_reward), ptr(ring.count), ptr(ring.frames), ptr(ring.r_reward), ptr(ring.r_action),
+          ptr(ring.r_terminal), ptr(ring.r_last_action), ptr(ring.r_last_reward), ptr(ring.r_pc),
+          ptr(out_reward), ptr(out_terminal), ptr(ring.episode_reward), ptr(ring.score_out),
+          ptr(ring.score_valid), int(reset_on_terminal), int(track_score))
+
+
+def pixel_change_u8(frames, idx_new, idx_old, denom, out):
+    N = idx_new.numel()
+    _chk(frames, "u8"); _chk(idx_new, "i32", N); _chk(idx_old, "i32", N); _chk(out, "f32", N * PC_CELLS)
+    _call("unreal_pixel_change_u8", N, ptr(frames), ptr(idx_new), ptr(idx_old), float(denom), ptr(out))
+
+
+def philox_uniform(seed, stream_id, out):
+    _chk(out, "f64")
+    _call("unreal_philox_uniform", int(seed), int(stream_id), out.numel(), ptr(out))
+
+
+def philox_randint(seed, stream_id, high, out):
+    _chk(out, "i32")
+    _call("unreal_philox_randint", int(seed), int(stream_id), out.numel(), int(high), ptr(out))
+
+
+# ---- replay --------------------------------------------------------------------------------------
+def replay_sample_seq(ring, L, start_draw, seq_idx, seq_len):
+    B = ring.B
+    _chk(start_draw, "i32", B); _chk(seq_idx, "i32", L * B); _chk(seq_len, "i32", B)
+    _call("unreal_replay_sample_seq", B, ring.H, ring.H1, L, ptr(start_draw), ptr(ring.count),
+          ptr(ring.r_terminal), ptr(seq_idx), ptr(seq_len))
+
+
+def replay_sample_rp(ring, coin, u, rp_idx, rp_class):
+    B = ring.B
+    _chk(coin, "i32", B); _chk(u, "f64", B); _chk(rp_idx, "i32", 3 * B); _chk(rp_class, "i32", B)
+    _call("unreal_replay_sample_rp", B, ring.H, ring.H1, ptr(coin), ptr(u), ptr(ring.count),
+          ptr(ring.r_reward), ptr(rp_idx), ptr(rp_class))
+
+
+def base_returns(B, T, rewards, values, n_steps, boot_v, terminal_end, gamma, R_out, adv_out):
+    for t in (rewards, values, R_out, adv_out):
+        _chk(t, "f32", B * T)
+    _chk(n_steps, "i32", B); _chk(boot_v, "f32", B); _chk(terminal_end, "i32", B)
+    _call("unreal_base_returns", B, T, ptr(rewards), ptr(values), ptr(n_steps), ptr(boot_v),
+          ptr(terminal_end), float(gamma), ptr(R_out), ptr(adv_out))
+
+
+def vr_returns(ring, L, seq_idx, seq_len, boot_v, gamma, R_out):
+    B = ring.B
+    _chk(seq_idx, "i32", L * B); _chk(seq_len, "i32", B); _chk(boot_v, "f32", B); _chk(R_out, "f32", (L - 1) * B)
+    _call("unreal_vr_returns", B, L, ptr(seq_idx), ptr(seq_len), ptr(ring.r_reward), ptr(ring.r_terminal),
+          ptr(boot_v), float(gamma), ptr(R_out))
+
+
+def pc_returns(ring, L, seq_idx, seq_len, boot_qmax, gamma_pc, R_out):
+    B = ring.B
+    _chk(seq_idx, "i32", L * B); _chk(seq_len, "i32", B); _chk(boot_qmax, "f32", B * PC_CELLS)
+    _chk(R_out, "f32", (L - 1) * B * PC_CELLS)
+    _call("unreal_pc_returns", B, L, ptr(seq_idx), ptr(seq_len), ptr(ring.r_pc), ptr(ring.r_terminal),
+          ptr(boot_qmax), float(gamma_pc), ptr(R_out))
+
+
+def lar_fill(rows, A, last_action, last_reward, idx, xcat, ld, col0=256):
+    _chk(last_action, "i32"); _chk(last_reward, "f32"); _chk(idx, "i32", rows, optional=True)
+    _chk(xcat, "f32", rows * ld)
+    if idx is None and (last_action.numel() < rows or last_reward.numel() < rows):
+        raise ValueError("lar_fill: per-row sources too short")
+    _call("unreal_lar_fill", rows, A, ptr(last_action), ptr(last_reward), ptr(idx), ptr(xcat), ld, col0)
+
+
+def gather_i32(src, idx, out):
+    _chk(src, "i32"); _chk(idx, "i32"); _chk(out, "i32", idx.numel())
+    _call("unreal_gather_i32", idx.numel(), ptr(src), ptr(idx), ptr(out))
+
+
+def rollout_advance(B, terminal_t, active, active_log_t, n_steps, terminal_end):
+    for t in (terminal_t, active, active_log_t, n_steps, terminal_end):
+        _chk(t, "i32", B)
+    _call("unreal_rollout_advance", B, ptr(terminal_t), ptr(active), ptr(active_log_t), ptr(n_steps),
+          ptr(terminal_end))
+
+
+def seq_mask(B, T, seq_len, mask):
+    _chk(seq_len, "i32", B); _chk(mask, "i32", B * T)
+    _call("unreal_seq_mask", B, T, ptr(seq_len), ptr(mask))
+
+
+def reset_state(B, terminal_end, c, h):
+    _chk(terminal_end, "i32", B); _chk(c, "f32", B * 256); _chk(h, "f32", B * 256)
+    _call("unreal_reset_state", B, ptr(terminal_end), ptr(c), ptr(h))
+
+
+# ---- network -------------------------------------------------------------------------------------
+def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None):
+    N = frame_idx.numel()
+    _chk(frames, "u8"); _chk(frame_idx, "i32", N)
+    _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192); _chk(b2, "f32", 32)
+    _chk(f2_out, "f32", N * F2_DIM); _chk(c1_out, "f32", N * C1_DIM, optional=True)
+    _call("unreal_encoder_fwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W1), ptr(b1), ptr(W2), ptr(b2),
+          ptr(c1_out), ptr(f2_out))
+
+
+def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2):
+    N = frame_idx.numel()
+    _chk(frames, "u8"); _chk(frame_idx, "i32", N); _chk(W2, "f32", 8192)
+    _chk(c1_saved, "f32", N * C1_DIM); _chk(d2, "f32", N * F2_DIM)
+    _chk(dW1, "f32", 3072); _chk(db1, "f32", 16); _chk(dW2, "f32", 8192); _chk(db2, "f32", 32)
+    _call("unreal_encoder_bwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W2), ptr(c1_saved), ptr(d2),
+          ptr(dW1), ptr(db1), ptr(dW2), ptr(db2))
+
+
+def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):
+    _chk(A, "f32", ((K - 1) * lda + M) if transA else ((M - 1) * lda + K), "A")
+    _chk(B, "f32", ((N - 1) * ldb + K) if transB else ((K - 1) * ldb + N), "B")
+    _chk(C, "f32", (M - 1) * ldc + N, "C")
+    _chk(bias, "f32", N, "bias", optional=True)
+    _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
+    _call("unreal_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias),
+          ptr(mask), ldm, flags, splitk)
+
+
+def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):
+    _chk(pre, "f32", rows * 1024); _chk(bias, "f32", 1024); _chk(c_prev, "f32", rows * 256)
+    _chk(gates_act, "f32", rows * 1024, optional=True); _chk(c_out, "f32", rows * 256)
+    _chk(h_out, "f32", (rows - 1) * ld_h + 256)
+    _call("unreal_lstm_gates_fwd", rows, ptr(pre), ptr(bias), ptr(c_prev), ptr(gates_act), ptr(c_out), ptr(h_out),
+          ld_h)
+
+
+def lstm_gates_bwd(rows, dh_above, dh_rec, dc_io, gates_act, c_prev, c_new, dpre):
+    _chk(dh_above, "f32", rows * 256); _chk(dh_rec, "f32", rows * 256, optional=True)
+    _chk(dc_io, "f32", rows * 256); _chk(gates_act, "f32", rows * 1024); _chk(c_prev, "f32", rows * 256)
+    _chk(c_new, "f32", rows * 256); _chk(dpre, "f32", rows * 1024)
+    _call("unreal_lstm_gates_bwd", rows, ptr(dh_above), ptr(dh_rec), ptr(dc_io), ptr(gates_act), ptr(c_prev),
+          ptr(c_new), ptr(dpre))
+
+
+def linear_small_fwd(rows, K, NOUT, X, ldx, W, b, out, ldo):
+    _chk(X, "f32", (rows - 1) * ldx + K); _chk(W, "f32", K * NOUT); _chk(b, "f32", NOUT)
+    _chk(out, "f32", (rows - 1) * ldo + NOUT)
+    _call("unreal_linear_small_fwd", rows, K, NOUT, ptr(X), ldx, ptr(W), ptr(b), ptr(out), ldo)
+
+
+def linear_small_bwd(rows, K, NOUT, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db):
+    _chk(X, "f32", (rows - 1) * ldx + K); _chk(dO, "f32", (rows - 1) * ldo + NOUT); _chk(W, "f32", K * NOUT)
+    _chk(dX, "f32", (rows - 1) * lddx + K, optional=True); _chk(dW, "f32", K * NOUT)
+    _chk(db, "f32", NOUT, optional=True)
+    _call("unreal_linear_small_bwd", rows, K, NOUT, ptr(X), ldx, ptr(dO), ldo, ptr(W), ptr(dX), lddx,
+          int(accumulate_dx), ptr(dW), ptr(db))
+
+
+def softmax_sample(rows, A, logits_pi, ld, u=None, action=None):
+    _chk(logits_pi, "f32", (rows - 1) * ld + A); _chk(u, "f64", rows, optional=True)
+    _chk(action, "i32", rows, optional=True)
+    _call("unreal_softmax_sample", rows, A, ptr(logits_pi), ld, ptr(u), ptr(action))
+
+
+def base_loss_grad(rows, A, pi, ld_pi, v, action, adv, R, active, beta, grad_scale, dlogits, dv, losses):
+    _chk(pi, "f32", (rows - 1) * ld_pi + A); _chk(v, "f32", rows); _chk(action, "i32", rows)
+    _chk(adv, "f32", rows); _chk(R, "f32", rows); _chk(active, "i32", rows)
+    _chk(dlogits, "f32", rows * A); _chk(dv, "f32", rows); _chk(losses, "f32", 3)
+    _call("unreal_base_loss_grad", rows, A, ptr(pi), ld_pi, ptr(v), ptr(action), ptr(adv), ptr(R), ptr(active),
+          float(beta), float(grad_scale), ptr(dlogits), ptr(dv), ptr(losses))
+
+
+def vr_loss_grad(rows, v, R, mask, grad_scale, dv, loss):
+    _chk(v, "f32", rows); _chk(R, "f32", rows); _chk(mask, "i32", rows); _chk(dv, "f32", rows); _chk(loss, "f32", 1)
+    _call("unreal_vr_loss_grad", rows, ptr(v), ptr(R), ptr(mask), float(grad_scale), ptr(dv), ptr(loss))
+
+
+def rp_loss_grad(rows, logits, cls, grad_scale, prob, dlogits, loss):
+    _chk(logits, "f32", rows * 3); _chk(cls, "i32", rows); _chk(prob, "f32", rows * 3, optional=True)
+    _chk(dlogits, "f32", rows * 3); _chk(loss, "f32", 1)
+    _call("unreal_rp_loss_grad", rows, ptr(logits), ptr(cls), float(grad_scale), ptr(prob), ptr(dlogits), ptr(loss))
+
+
+def colsum(rows, cols, X, ld, out):
+    _chk(X, "f32", (rows - 1) * ld + cols); _chk(out, "f32", cols)
+    _call("unreal_colsum", rows, cols, ptr(X), ld, ptr(out))
+
+
+def relu_mask(rows, cols, d, ldd, src, lds):
+    _chk(d, "f32", (rows - 1) * ldd + cols); _chk(src, "f32", (rows - 1) * lds + cols)
+    _call("unreal_relu_mask", rows, cols, ptr(d), ldd, ptr(src), lds)
+
+
+def pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, qmax=None, action=None, target=None, mask=None, lam=0.0,
+                  grad_scale=1.0, d_dec=None, loss=None):
+    _chk(hp, "f32", N * F2_DIM); _chk(Wv, "f32", 512); _chk(bv, "f32", 1); _chk(Wa, "f32", 512 * A); _chk(ba, "f32", A)
+    _chk(qmax, "f32", N * PC_CELLS, optional=True); _chk(action, "i32", N, optional=True)
+    _chk(target, "f32", N * PC_CELLS, optional=True); _chk(mask, "i32", N, optional=True)
+    _chk(d_dec, "f32", N * PC_CELLS * (1 + A), optional=True); _chk(loss, "f32", 1, optional=True)
+    _call("unreal_pc_deconv_fwd", N, A, ptr(hp), ptr(Wv), ptr(bv), ptr(Wa), ptr(ba), ptr(qmax), ptr(action),
+          ptr(target), ptr(mask), float(lam), float(grad_scale), ptr(d_dec), ptr(loss))
+
+
+def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba):
+    _chk(hp, "f32", N * F2_DIM); _chk(d_dec, "f32", N * PC_CELLS * (1 + A)); _chk(Wv, "f32", 512)
+    _chk(Wa, "f32", 512 * A); _chk(d_hp, "f32", N * F2_DIM); _chk(dWv, "f32", 512); _chk(dbv, "f32", 1)
+    _chk(dWa, "f32", 512 * A); _chk(dba, "f32", A)
+    _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(d_dec), ptr(Wv), ptr(Wa), ptr(d_hp), ptr(dWv), ptr(dbv),
+          ptr(dWa), ptr(dba))
+
+
+# ---- optimiser -----------------------------------------------------------------------------------
+def grad_norm(grad, scratch, norm_out):
+    _chk(grad, "f32"); _chk(scratch, "f32", 256); _chk(norm_out, "f32", 1)
+    _call("unreal_grad_norm", ptr(grad), grad.numel(), ptr(scratch), ptr(norm_out))
+
+
+def rmsprop_step(var, ms, mom, grad, lr, decay, momentum, eps, clip_norm, norm):
+    n = var.numel()
+    _chk(var, "f32"); _chk(ms, "f32", n); _chk(mom, "f32", n); _chk(grad, "f32", n)
+    _chk(norm, "f32", 1, optional=True)
+    _call("unreal_rmsprop_step", ptr(var), ptr(ms), ptr(mom), ptr(grad), n, float(lr), float(decay),
+          float(momentum), float(eps), float(clip_norm), ptr(norm))
