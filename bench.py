@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of full-UNREAL `Trainer.process()` on maze 84x84 (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one `Trainer.process()` call: every actor of the rank is advanced by n_step_TD = 20
+environment steps (HIP env kernel writing straight into the HBM replay ring), then one UNREAL update
+(base A3C + pixel control + value replay + reward prediction, hand-written forward/backward kernels,
+fused clip + RMSProp; gradient all-reduce over RCCL when N > 1).  Workload = BASELINE.json configs[1]:
+4096 batched actors per MI355X, replay history 2000 frames per actor (173 GB uint8 ring), fp32 compute.
+value = env steps taken by ALL ranks inside the K timed calls / max-over-ranks wall time.  The replay
+fill (2000 policy steps per actor, no learning -- the reference's global_t does not advance there
+either, trainer.py:446-448) and W warm-up calls are untimed.
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (HIP-event timed inside the timed
+region) and `cpu_baseline` (the oracle's threaded restatement of the reference loop on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per launch unit (DESIGN.md section "Kernels"); MACs per frame
+ENC_FWD_MAC = 400 * 192 * 16 + 81 * 256 * 32                     # conv1 + conv2 forward
+ENC_BWD_MAC = 81 * 256 * 32 * 2 + 400 * 192 * 16                 # conv2 wgrad + dgrad, conv1 wgrad
+FP32_MFMA_PEAK_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0
+
+
+def build_trainer(args, rank, world, device):
+    from unreal_amd.environment.environment import Environment
+    from unreal_amd.model.model import UnrealModel
+    from unreal_amd.options import get_options
+    from unreal_amd.train.rmsprop_applier import RMSPropApplier
+    from unreal_amd.train.trainer import Trainer, log_uniform
+    from unreal_amd import parallel
+    flags = get_options("training", preset="lab", argv=["--env_type", "maze", "--env_name", ""])
+    Environment.action_size = -1
+    A = Environment.get_action_size("maze", "")
+    net = UnrealModel(A, 0, -1, flags.use_lstm, flags.use_pixel_change, flags.use_value_replay,
+                      flags.use_reward_prediction, flags.pixel_change_lambda, flags.entropy_beta, device, seed=1)
+    lr0 = log_uniform(flags.initial_alpha_low, flags.initial_alpha_high, flags.initial_alpha_log_rate)
+    applier = RMSPropApplier(None, decay=flags.rmsp_alpha, momentum=0.0, epsilon=flags.rmsp_epsilon,
+                             clip_norm=flags.grad_norm_clip, device=device)
+    tr = Trainer(0 if rank == 0 else rank, net, lr0, None, applier, "maze", "", flags.use_lstm,
+                 flags.use_pixel_change, flags.use_value_replay, flags.use_reward_prediction,
+                 flags.pixel_change_lambda, flags.entropy_beta, flags.local_t_max, flags.n_step_TD, flags.gamma,
+                 flags.gamma_pc, args.history, flags.max_time_step, device, batch_size=args.actors,
+                 world_size=world, rank=rank, seed=0xA3C,
+                 grad_sync=parallel.all_reduce_sum if world > 1 else None)
+    tr.prepare()
+    return flags, net, tr
+
+
+def cpu_baseline(seconds, threads, history):
+    """The oracle's restatement of the reference's threaded loop (main.py:72-162 + trainer.py:438-636):
+    `threads` Python threads, each one actor with batch-1 forwards, numpy maze, deque-like replay, its own
+    gradient and a hogwild RMSProp step on shared parameters; PyTorch-CPU fp32, one intra-op thread."""
+    from oracle.trainer import OracleTrainer
+    torch.set_num_threads(1)
+    cfg = dict(action_size=4, use_lstm=True, use_pixel_change=True, use_value_replay=True,
+               use_reward_prediction=True, pixel_change_lambda=0.05, entropy_beta=0.001, local_t_max=20,
+               n_step_TD=20, gamma=0.99, gamma_pc=0.9, experience_history_size=history,
+               max_time_step=int(13.2e6), rmsp_alpha=0.99, rmsp_epsilon=0.1, grad_norm_clip=40.0,
+               initial_alpha_low=1e-4, initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
+    tr = OracleTrainer(cfg, n_actors=threads, seed=1)
+    tr.fill()
+    steps = [0] * threads
+    stop = time.time() + seconds
+    t0 = time.time()
+
+    def work(i):
+        while time.time() < stop:
+            d, _, _ = tr.process_async(i, sum(steps))
+            steps[i] += d
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    el = time.time() - t0
+    return sum(steps) / el, sum(steps), el
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--actors", type=int, default=4096, help="actors per GPU (BASELINE.json configs[1])")
+    ap.add_argument("--history", type=int, default=2000, help="experience_history_size per actor")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=8, help="parallel_size of the reference (options.py:37)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-kernel", default="unreal_encoder_bwd")
+    args = ap.parse_args()
+
+    from unreal_amd import parallel, ops
+    rank, local_rank, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    flags, net, tr = build_trainer(args, rank, world, device)
+    T = flags.n_step_TD
+
+    t_fill = time.time()
+    while not tr._full:                      # replay warm-up: untimed, global_t frozen
+        tr.process(None, 0)
+    torch.cuda.synchronize()
+    t_fill = time.time() - t_fill
+
+    global_t = 0
+    for _ in range(args.warmup):
+        tr.process(None, global_t, sync_stats=False)
+        global_t += args.actors * T * world
+    tr.read_stats()
+    ops.kernel_timer_start(args.timed_kernel)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.process(None, global_t, sync_stats=False)
+        global_t += args.actors * T * world
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    kt = ops.kernel_timer_stop()
+    steps_local, episodes, score_sum = tr.read_stats()
+    elapsed = parallel.max_over_ranks(elapsed, device)
+    tot_steps, tot_eps, tot_score = parallel.sum_over_ranks([steps_local, episodes, score_sum], device)
+    losses = tr._publish_losses()
+
+    if rank != 0:
+        return
+    value = tot_steps / elapsed
+    frames_per_launch = kt["units"] / max(kt["launches"], 1)
+    mac = ENC_BWD_MAC if "bwd" in args.timed_kernel else ENC_FWD_MAC
+    avg_ms = kt["ms"] / max(kt["launches"], 1)
+    achieved = (2.0 * mac * frames_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "env-steps/sec (whole node), UNREAL maze 84x84",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (device maze environments, random-init weights)",
+        "config": {"workload": "maze_environment full UNREAL (PC+RP+VR), %d batched actors per MI355X, "
+                               "n_step_TD=%d, replay history %d/actor (uint8 HBM ring)" % (args.actors, T, args.history),
+                   "actors_per_gpu": args.actors, "global_actors": args.actors * world,
+                   "env_steps_per_call": tot_steps / args.steps, "parallelism": "actors sharded x%d, flat-gradient "
+                   "all-reduce" % world if world > 1 else "single GPU", "replay_fill_s": t_fill,
+                   "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
+        "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "launches": kt["launches"], "avg_launch_ms": avg_ms,
+                     "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),
+                     "whole_path_frac_fp32_mfma": value * 69.67e6 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world),
+                     "whole_path_frac_hbm_u8": value * 114396.0 / (HBM_PEAK_GBS * 1e9 * world)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        hist_cpu = 200
+        v, s, el = cpu_baseline(args.cpu_seconds, args.cpu_threads, hist_cpu)
+        out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": args.cpu_threads, "kind": "port",
+                               "host_cores": os.cpu_count(),
+                               "sample": "%d env-steps in %.1f s: %d Python threads x full-UNREAL process() "
+                                         "(oracle/trainer.py, PyTorch-CPU fp32, 1 intra-op thread each), replay "
+                                         "history %d/thread (fill untimed)" % (s, el, args.cpu_threads, hist_cpu)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

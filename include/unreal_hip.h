@@ -71,6 +71,11 @@ int unreal_rollout_advance(int B, const int* terminal_t, int* active, int* activ
 int unreal_seq_mask(int B, int T, const int* seq_len, int* mask, void* stream);
 int unreal_reset_state(int B, const int* terminal_end, float* c, float* h, void* stream);
 int unreal_ring_cur_idx(int B, int H1, const int* count, int* out /*[B]*/, void* stream);
+int unreal_seq_last_idx(int B, const int* seq_idx, const int* seq_len, int* out /*[B]*/, void* stream);
+/* stats[3] (double) += {env steps, finished episodes, sum of their scores}; clears score_valid
+ * (train/trainer.py:635-636 return value) */
+int unreal_rollout_stats(int B, const int* n_steps, int* score_valid, const float* score_out, double* stats,
+                         void* stream);
 
 /* ---- conv encoder (model/model.py:281-289,786-787) and its gradient ------------------------------ */
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,

@@ -1,0 +1,233 @@
+"""End-to-end parity (GPU): the batched `Trainer.process()` on HIP kernels vs the CPU oracle running the
+reference algorithm actor by actor (oracle/trainer.py, fp64 as arbiter) on the SAME parameters and the
+SAME random draws (the device Philox draws are recorded and replayed into the oracle).
+
+Checked per update: per-actor step counts and actions (exact), rewards / terminals (exact), the eight
+loss scalars, the mean gradient of every variable, the pre-clip global norm and the parameters after
+the RMSProp step.  Tolerances (fp32 kernels vs fp64 oracle) are written at each assert."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import maze as OM
+from oracle.trainer import OracleTrainer, ExplicitDraws
+
+DEV = "cuda:0"
+
+
+class RecordingDraws(object):
+    def __init__(self, inner):
+        self.inner = inner
+        self.log = []
+
+    def uniform(self, out):
+        self.inner.uniform(out)
+        self.log.append(out.cpu().numpy().copy())
+        return out
+
+    def randint(self, high, out):
+        self.inner.randint(high, out)
+        self.log.append(out.cpu().numpy().copy())
+        return out
+
+
+def _cfg(use_lstm, aux, H, T):
+    return dict(action_size=4, use_lstm=use_lstm, use_pixel_change=aux, use_value_replay=aux,
+                use_reward_prediction=aux, pixel_change_lambda=0.05, entropy_beta=0.001, local_t_max=T,
+                n_step_TD=T, gamma=0.99, gamma_pc=0.9, experience_history_size=H, max_time_step=10 ** 6,
+                rmsp_alpha=0.99, rmsp_epsilon=0.1, grad_norm_clip=40.0, initial_alpha_low=1e-4,
+                initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
+
+
+def _build(cfg, B, seed):
+    from unreal_amd.environment.environment import Environment
+    from unreal_amd.model.model import UnrealModel
+    from unreal_amd.train.rmsprop_applier import RMSPropApplier
+    from unreal_amd.train.trainer import Trainer, PhiloxDraws
+    Environment.action_size = -1
+    net = UnrealModel(4, 0, -1, cfg["use_lstm"], cfg["use_pixel_change"], cfg["use_value_replay"],
+                      cfg["use_reward_prediction"], cfg["pixel_change_lambda"], cfg["entropy_beta"], DEV, seed=seed)
+    applier = RMSPropApplier(None, decay=cfg["rmsp_alpha"], momentum=0.0, epsilon=cfg["rmsp_epsilon"],
+                             clip_norm=cfg["grad_norm_clip"], device=DEV)
+    draws = RecordingDraws(PhiloxDraws(0xA3C, 0))
+    tr = Trainer(0, net, 7.0711e-4, None, applier, "maze", "", cfg["use_lstm"], cfg["use_pixel_change"],
+                 cfg["use_value_replay"], cfg["use_reward_prediction"], cfg["pixel_change_lambda"],
+                 cfg["entropy_beta"], cfg["local_t_max"], cfg["n_step_TD"], cfg["gamma"], cfg["gamma_pc"],
+                 cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws)
+    tr.prepare()
+    return net, applier, tr, draws
+
+
+def _teleport(tr, orc, b, x, y):
+    """Put actor b at cell (x,y) on both sides (to provoke terminals inside a rollout)."""
+    ring = tr.ring
+    from unreal_amd import ops
+    cnt = int(ring.count.cpu()[b])
+    slot = b * ring.H1 + cnt % ring.H1
+    img = OM.render(x, y)
+    ring.frames[slot * ops.FRAME_BYTES:(slot + 1) * ops.FRAME_BYTES].copy_(
+        torch.from_numpy(img.astype(np.uint8).reshape(-1)))
+    pos = ring.pos.cpu()
+    pos[2 * b], pos[2 * b + 1] = x, y
+    ring.pos.copy_(pos)
+    env = orc.actors[b].env
+    env.x, env.y = x, y
+    env.last_state = {'image': img}
+
+
+@pytest.mark.parametrize("use_lstm,aux", [(True, True), (False, False)])
+def test_process_matches_oracle(use_lstm, aux):
+    B, H, T = 3, 40, 20
+    cfg = _cfg(use_lstm, aux, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    net, applier, tr, draws = _build(cfg, B, seed=3)
+    named = net.export_named()
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in named.items()}
+    edraws = [ExplicitDraws() for _ in range(B)]
+    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params)
+
+    # ---- replay fill ------------------------------------------------------------------------------
+    calls = 0
+    while not tr._full:
+        d, s = tr.process(None, 0)
+        assert (d, s) == (0, None)
+        calls += 1
+    assert calls == H
+    assert len(draws.log) == H
+    for step_u in draws.log:
+        for b in range(B):
+            edraws[b].action_u.append(float(step_u[b]))
+    orc.fill()
+    assert all(len(e.action_u) == 0 for e in edraws)
+    np.testing.assert_array_equal(tr.ring.count.cpu().numpy(), [a.exp.count for a in orc.actors])
+    for b in range(B):
+        a = orc.actors[b]
+        assert tuple(tr.ring.pos.cpu().numpy()[2 * b:2 * b + 2]) == (a.env.x, a.env.y) == OM.START
+
+    global_t = 0
+    for it in range(4):
+        if it == 1:
+            _teleport(tr, orc, 0, 5, 0)      # one RIGHT from the goal
+            _teleport(tr, orc, 1, 4, 0)
+        draws.log.clear()
+        lr = tr._anneal_learning_rate(global_t)
+        tr.compute_gradients()
+        g_dev = {k: v.detach().cpu().double().numpy().copy() for k, v in net.g.items()}
+        norm_dev = float(applier.step(net.params.flat, net.grads.flat, lr).cpu()[0])
+        tr.stats.zero_()
+        from unreal_amd import ops
+        ops.rollout_stats(B, tr.n_steps, tr.ring.score_valid, tr.ring.score_out, tr.stats)
+        steps_dev, episodes_dev, score_dev = tr.read_stats()
+        losses_dev = tr._publish_losses()
+
+        # replay the draws into the oracle
+        u_act = draws.log[0].reshape(T, B)
+        k = 1
+        for b in range(B):
+            edraws[b].action_u = [float(u_act[t, b]) for t in range(T)]
+            edraws[b].seq_starts = []
+            edraws[b].rp_coin, edraws[b].rp_u = [], []
+        if aux:
+            for b in range(B):
+                edraws[b].seq_starts = [int(draws.log[1][b]), int(draws.log[2][b])]
+                edraws[b].rp_coin = [int(draws.log[3][b])]
+                edraws[b].rp_u = [float(draws.log[4][b])]
+        steps_o, infos, losses_o, mean_g, norm_o = orc.process_batched(global_t)
+
+        # ---- exact: step counts, actions, rewards, terminals ------------------------------------
+        n_dev = tr.n_steps.cpu().numpy()
+        acts = tr.actions.cpu().numpy().reshape(T, B)
+        rews = tr.rewards.cpu().numpy().reshape(T, B)
+        assert steps_dev == steps_o == int(n_dev.sum())
+        for b in range(B):
+            n = infos[b]["n"]
+            assert n_dev[b] == n
+            assert list(acts[:n, b]) == infos[b]["actions"]
+            assert list(rews[:n, b]) == [float(r) for r in infos[b]["rewards"]]
+            assert bool(tr.terminal_end.cpu()[b]) == infos[b]["terminal_end"]
+        sc = [i["score"] for i in infos if i["score"] is not None]
+        assert episodes_dev == len(sc)
+        if sc:
+            assert abs(score_dev - sum(sc)) < 1e-6
+        if it == 1:
+            assert episodes_dev >= 1, "teleported actors should finish an episode (ragged rollout is covered)"
+
+        # ---- losses: mean over actors of the per-actor sums; |d| <= 2e-4 abs + 2e-4 rel ----------
+        for key in ("policy_loss", "value_loss", "pc_loss", "vr_loss", "rp_loss", "total_loss"):
+            if key in losses_o[0]:
+                want = np.mean([l[key] for l in losses_o])
+                assert abs(losses_dev[key] - want) <= 2e-4 + 2e-4 * abs(want), (it, key, losses_dev[key], want)
+        want_ent = np.mean([l["entropy"].sum() for l in losses_o])
+        assert abs(losses_dev["entropy"] - want_ent) <= 2e-4 + 2e-4 * abs(want_ent)
+
+        # ---- gradients: per variable, |d| <= 1e-5 + 2e-4 * max|g_ref| ---------------------------
+        for (name, _), gref in zip(orc.params.items(), mean_g):
+            gr = gref.numpy().reshape(-1)
+            gd = g_dev[name]
+            tol = 1e-5 + 2e-4 * np.abs(gr).max()
+            assert np.abs(gd - gr).max() <= tol, (it, name, np.abs(gd - gr).max(), np.abs(gr).max())
+        assert abs(norm_dev - norm_o) <= 1e-4 * max(1.0, norm_o), (norm_dev, norm_o)
+
+        # ---- parameters after the update: |d| <= 2e-6 + 1e-5 rel --------------------------------
+        for name, ref in orc.params.items():
+            got = net.p[name].cpu().double().numpy()
+            want = ref.numpy().reshape(-1)
+            assert np.abs(got - want).max() <= 2e-6 + 1e-5 * np.abs(want).max(), (it, name)
+        global_t += steps_dev
+    assert all(len(e.seq_starts) == 0 and len(e.rp_u) == 0 for e in edraws)
+
+
+def test_batch1_runners_match_oracle():
+    """Reference-shaped batch-1 entry points (model.py:630-728) against the oracle network."""
+    from oracle import model as M
+    cfg = _cfg(True, True, 40, 20)
+    net, applier, tr, draws = _build(cfg, 2, seed=5)
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+    env = OM.OracleMaze()
+    rs = np.random.RandomState(0)
+    state = (torch.zeros(256, dtype=torch.float64), torch.zeros(256, dtype=torch.float64))
+    net.reset_state()
+    for step in range(3):
+        lar = np.zeros(5)
+        lar[env.last_action] = 1.0
+        lar[4] = env.last_reward
+        x = torch.tensor(env.last_state['image']).unsqueeze(0)
+        tl = torch.tensor(lar).unsqueeze(0)
+        feat, st = M.trunk(x, tl, p, True, state)
+        pi_o, v_o = M.policy_value(feat, p)
+        v_only = net.run_base_value(None, env.last_state, lar)
+        pi, v, _ = net.run_base_policy_and_value(None, env.last_state, lar)
+        np.testing.assert_allclose(pi, pi_o[0].numpy(), atol=2e-6, rtol=1e-5)
+        assert abs(v - float(v_o[0])) < 2e-5 and abs(v_only - float(v_o[0])) < 2e-5
+        fz, _ = M.trunk(x, tl, p, True, None)
+        _, qm = M.pc_head(fz, p)
+        np.testing.assert_allclose(net.run_pc_q_max(None, env.last_state, lar), qm[0].numpy(), atol=2e-5, rtol=2e-5)
+        _, vz = M.policy_value(fz, p)
+        assert abs(net.run_vr_value(None, env.last_state, lar) - float(vz[0])) < 2e-5
+        state = st
+        env.process(int(rs.randint(4)))
+    hist = [{'image': OM.render(0, 2)}, {'image': OM.render(1, 2)}, {'image': OM.render(1, 3)}]
+    rp_o = M.rp_head(torch.tensor(np.stack([h['image'] for h in hist])), p)
+    np.testing.assert_allclose(net.run_rp_c(None, hist), rp_o[0].numpy(), atol=2e-6, rtol=1e-5)
+
+
+def test_maze_environment_reference_surface():
+    """The reference's own environment test (environment/environment_test.py:36-54) with the documented
+    adapter (last_state is a dict with 'image')."""
+    from unreal_amd.environment.environment import Environment
+    Environment.action_size = -1
+    env = Environment.create_environment("maze", "")
+    assert Environment.get_action_size("maze", "") == 4
+    ref = OM.OracleMaze()
+    for a in (0, 0, 0, 3, 1, 1):
+        state, reward, terminal, pc = env.process(a)
+        _, r2, t2, pc2 = ref.process(a)
+        assert state.shape == (84, 84, 3) and env.last_state['image'].shape == (84, 84, 3)
+        assert pc.shape == (20, 20)
+        assert 0.0 <= state.min() and state.max() <= 1.0 and 0.0 <= pc.min() and pc.max() <= 1.0
+        np.testing.assert_array_equal(state, ref.last_state['image'])
+        np.testing.assert_array_equal(pc, pc2.astype(np.float32))
+        assert (reward, terminal) == (r2, t2)
+    env.stop()

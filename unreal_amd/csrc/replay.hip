@@ -185,6 +185,30 @@ __global__ void ring_cur_idx_kernel(int B, int H1, const int* count, int* out) {
   if (b < B) out[b] = b * H1 + count[b] % H1;
 }
 
+// bootstrap frame of every sampled sequence: the LAST sampled frame (trainer.py:356-358, 396-398)
+__global__ void seq_last_idx_kernel(int B, const int* seq_idx, const int* seq_len, int* out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = seq_idx[(size_t)(seq_len[b] - 1) * B + b];
+}
+
+// stats[0] += env steps taken, stats[1] += finished episodes, stats[2] += sum of their scores;
+// clears score_valid (one launch per process(): trainer.py:635-636 return value)
+__global__ void rollout_stats_kernel(int B, const int* n_steps, int* score_valid, const float* score_out,
+                                     double* stats) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0.0, e = 0.0, sc = 0.0;
+  if (b < B) {
+    s = (double)n_steps[b];
+    if (score_valid[b]) { e = 1.0; sc = (double)score_out[b]; score_valid[b] = 0; }
+  }
+  s = wave_sum_d(s); e = wave_sum_d(e); sc = wave_sum_d(sc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(stats + 0, s);
+    atomicAdd(stats + 1, e);
+    atomicAdd(stats + 2, sc);
+  }
+}
+
 }  // namespace
 
 #define GRID1(n) dim3(((n) + 255) / 256), dim3(256), 0, (hipStream_t)stream
@@ -263,6 +287,19 @@ int unreal_seq_mask(int B, int T, const int* seq_len, int* mask, void* stream) {
 int unreal_ring_cur_idx(int B, int H1, const int* count, int* out, void* stream) {
   if (B <= 0 || H1 < 2 || !count || !out) return UNREAL_EINVAL;
   hipLaunchKernelGGL(ring_cur_idx_kernel, GRID1(B), B, H1, count, out);
+  return unreal_launch_status();
+}
+
+int unreal_seq_last_idx(int B, const int* seq_idx, const int* seq_len, int* out, void* stream) {
+  if (B <= 0 || !seq_idx || !seq_len || !out) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(seq_last_idx_kernel, GRID1(B), B, seq_idx, seq_len, out);
+  return unreal_launch_status();
+}
+
+int unreal_rollout_stats(int B, const int* n_steps, int* score_valid, const float* score_out, double* stats,
+                         void* stream) {
+  if (B <= 0 || !n_steps || !score_valid || !score_out || !stats) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(rollout_stats_kernel, GRID1(B), B, n_steps, score_valid, score_out, stats);
   return unreal_launch_status();
 }
 

@@ -1,0 +1,376 @@
+"""UnrealModel on MI355X: the reference's network surface over hand-written gfx950 kernels.
+
+Mirrors /root/reference/model/model.py (vanilla encoder, segnet_mode == 0):
+  ctor 49-66, prepare_loss 579-598, run_base_policy_and_value 630-660, run_base_value 687-704,
+  run_pc_q_max 707-712, run_vr_value 715-720, run_rp_c 723-728, get_vars 731, sync_from 737-749,
+  reset_state 625-628; initialisers 31-42, 752-783.
+Parameters live in ONE flat fp32 device buffer (TF layouts, TF creation order, each variable
+padded to a 64-float boundary so 16 B vector loads stay aligned); `get_vars()` returns views.
+The batched entry points (`trunk_forward`, `trunk_backward`, ...) are what `Trainer` drives; the
+batch-1 `run_*` methods keep the reference call shapes for evaluate/display-style callers.
+
+There is no CPU fallback: every method launches kernels of libunreal_hip.so.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import ops
+
+ALIGN = 64
+XLD = 264          # row stride of the [fc(256) | last_action_reward | pad] LSTM input buffer
+
+
+def param_spec(action_size, objective_size=0, use_lstm=True, use_pixel_change=True,
+               use_value_replay=True, use_reward_prediction=True):
+    """(name, shape, fan_in) in the reference's variable-creation order (model.py:106-136)."""
+    A = action_size
+    lstm_in = 256 + A + 1 + objective_size
+    spec = [("W_base_conv1", (8, 8, 3, 16), 192), ("b_base_conv1", (16,), 192),
+            ("W_base_conv2", (4, 4, 16, 32), 256), ("b_base_conv2", (32,), 256),
+            ("W_base_fc1", (2592, 256), 2592), ("b_base_fc1", (256,), 2592)]
+    if use_lstm:
+        spec += [("lstm_kernel", (lstm_in + 256, 1024), None), ("lstm_bias", (1024,), 0)]
+    spec += [("W_base_fc_p", (256, A), 256), ("b_base_fc_p", (A,), 256),
+             ("W_base_fc_v", (256, 1), 256), ("b_base_fc_v", (1,), 256)]
+    if use_pixel_change:
+        spec += [("W_pc_fc1", (256, 2592), 256), ("b_pc_fc1", (2592,), 256),
+                 ("W_pc_deconv_v", (4, 4, 1, 32), 512), ("b_pc_deconv_v", (1,), 512),
+                 ("W_pc_deconv_a", (4, 4, A, 32), 512), ("b_pc_deconv_a", (A,), 512)]
+    if use_reward_prediction:
+        spec += [("W_rp_fc1", (7776, 3), 7776), ("b_rp_fc1", (3,), 7776)]
+    return spec
+
+
+class FlatParams(object):
+    """One flat buffer + named views; the same layout is used for grads and RMSProp slots."""
+
+    def __init__(self, spec, device):
+        self.spec = spec
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape, _ in spec:
+            n = int(np.prod(shape))
+            self.offsets[name] = (off, n, shape)
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.size = off
+        self.n_params = sum(n for _, n, _ in self.offsets.values())
+        self.flat = torch.zeros(self.size, dtype=torch.float32, device=device)
+        self.views = self.make_views(self.flat)
+
+    def make_views(self, flat):
+        return OrderedDict((k, flat[o:o + n]) for k, (o, n, _) in self.offsets.items())
+
+    def shaped(self, name):
+        o, n, shape = self.offsets[name]
+        return self.flat[o:o + n].view(shape)
+
+
+class PathWS(object):
+    """Activations of one trunk pass over `rows` frames (time-major rows t*B + b)."""
+
+    def __init__(self, rows, B, device, save_c1=True, lstm=True):
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
+        self.rows, self.B = rows, B
+        self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
+        self.c1 = f(rows * ops.C1_DIM) if save_c1 else None
+        self.f2 = f(rows * ops.F2_DIM)
+        self.xcat = torch.zeros(rows * XLD, dtype=torch.float32, device=device)
+        if lstm:
+            self.gates = f(rows * 1024)
+            self.c = f(rows * 256)
+            self.h = f(rows * 256)
+            self.c0 = torch.zeros(B * 256, dtype=torch.float32, device=device)
+            self.h0 = torch.zeros(B * 256, dtype=torch.float32, device=device)
+
+
+class GradWS(object):
+    """Gradient temporaries shared by all paths (sized for the largest)."""
+
+    def __init__(self, rows, B, device, lstm=True, pc=True, A=4):
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
+        self.d_feat = f(rows * 256)
+        self.d_fc = f(rows * 256)
+        self.d_f2 = f(rows * ops.F2_DIM)
+        if lstm:
+            self.d_gates = f(rows * 1024)
+            self.dh_rec = f(B * 256)
+            self.dc = f(B * 256)
+        if pc:
+            self.hp = f(rows * ops.F2_DIM)
+            self.d_dec = f(rows * ops.PC_CELLS * (1 + A))
+            self.pc_R = f(rows * ops.PC_CELLS)
+
+
+def _splitk(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = (K + 31) // 32
+    return max(1, min(nk // 4 if nk >= 8 else 1, (1024 + tiles - 1) // tiles))
+
+
+class UnrealModel(object):
+    """UNREAL network (reference ctor signature kept; TF-only arguments are accepted and ignored)."""
+
+    def __init__(self, action_size, objective_size, thread_index, use_lstm, use_pixel_change,
+                 use_value_replay, use_reward_prediction, pixel_change_lambda, entropy_beta, device,
+                 segnet_param_dict=None, image_shape=(84, 84), is_training=True, n_classes=0,
+                 segnet_lambda=1.0, dropout=0.0, for_display=False, frame_scale=1.0, seed=0):
+        if objective_size != 0:
+            raise NotImplementedError("objective vectors (indoor_environment) are outside this round's scope")
+        if segnet_param_dict is not None and segnet_param_dict.get("segnet_mode", 0) not in (0, None):
+            raise NotImplementedError("only the vanilla encoder (segnet_mode == 0) is on the hot path")
+        if tuple(image_shape) != (84, 84):
+            raise ValueError("the conv encoder kernels are specialised for 84x84x3 frames")
+        self._device = torch.device(device if device not in (None, "/gpu:0", "/cpu:0") else "cuda:0")
+        self._action_size = action_size
+        self._objective_size = objective_size
+        self._thread_index = thread_index
+        self._use_lstm = use_lstm
+        self._use_pixel_change = use_pixel_change
+        self._use_value_replay = use_value_replay
+        self._use_reward_prediction = use_reward_prediction
+        self._pixel_change_lambda = pixel_change_lambda
+        self._entropy_beta = entropy_beta
+        self.frame_scale = float(frame_scale)
+        self.spec = param_spec(action_size, objective_size, use_lstm, use_pixel_change, use_value_replay,
+                               use_reward_prediction)
+        self.params = FlatParams(self.spec, self._device)
+        self.grads = FlatParams(self.spec, self._device)
+        self.p = self.params.views
+        self.g = self.grads.views
+        self._init_weights(seed)
+        self.variables = [self.params.shaped(n) for n, _, _ in self.spec]
+        self.reset_state()
+        # loss attributes of the reference (populated by Trainer after every update)
+        self.total_loss = self.base_loss = self.policy_loss = self.value_loss = None
+        self.entropy = self.pc_loss = self.vr_loss = self.rp_loss = None
+        self._b1 = None
+
+    # -- parameters ---------------------------------------------------------------------------------
+    def _init_weights(self, seed):
+        """U(+-1/sqrt(fan_in)) for W and b (model.py:31-42,752-783); LSTM kernel glorot_uniform, bias 0."""
+        rs = np.random.RandomState(seed)
+        for name, shape, fan_in in self.spec:
+            if fan_in is None:
+                lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+                v = rs.uniform(-lim, lim, size=shape)
+            elif fan_in == 0:
+                v = np.zeros(shape)
+            else:
+                d = 1.0 / math.sqrt(fan_in)
+                v = rs.uniform(-d, d, size=shape)
+            self.p[name].copy_(torch.as_tensor(v.reshape(-1), dtype=torch.float32))
+
+    def load_named(self, named):
+        """Load {name: array} (TF layouts), e.g. parameters exported by another implementation."""
+        for k, v in named.items():
+            self.p[k].copy_(torch.as_tensor(np.asarray(v, dtype=np.float32).reshape(-1)))
+
+    def export_named(self):
+        return OrderedDict((n, self.params.shaped(n).detach().cpu().numpy().copy()) for n, _, _ in self.spec)
+
+    def get_vars(self):
+        return self.variables
+
+    def get_global_vars(self):
+        return self.variables
+
+    def sync_from(self, src_network, name=None):
+        """global -> local copy (model.py:737-749).  One parameter copy per GPU: nothing to do."""
+        if src_network is not self:
+            self.params.flat.copy_(src_network.params.flat)
+        return None
+
+    def prepare_loss(self):
+        return None
+
+    def reset_state(self):
+        z = torch.zeros(256, dtype=torch.float32, device=self._device)
+        self.base_lstm_state_out = (z, z.clone())     # (c, h) like LSTMStateTuple
+
+    # -- batched building blocks -----------------------------------------------------------------------
+    def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True):
+        """conv encoder -> fc (+ last_action_reward columns and the input half of the LSTM gates) for rows
+        [row0, row0+nrows) of a path workspace."""
+        p = self.p
+        idx = ws.frame_idx[row0:row0 + nrows]
+        f2 = ws.f2[row0 * ops.F2_DIM:]
+        xcat = ws.xcat[row0 * XLD:]
+        c1 = ws.c1[row0 * ops.C1_DIM:] if (save_c1 and ws.c1 is not None) else None
+        ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
+                        p["W_base_conv2"], p["b_base_conv2"], f2, c1)
+        ops.gemm(0, 0, nrows, 256, 2592, f2, 2592, p["W_base_fc1"], 256, xcat, XLD, bias=p["b_base_fc1"],
+                 flags=ops.GEMM_RELU)
+        if not self._use_lstm:
+            return
+        A = self._action_size
+        if lar_from_ring:
+            ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, XLD)
+        else:
+            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, XLD)
+        ops.gemm(0, 0, nrows, 1024, 256 + A + 1, xcat, XLD, p["lstm_kernel"], 1024, ws.gates[row0 * 1024:], 1024)
+
+    def lstm_step(self, ws, t, B):
+        """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math)."""
+        p = self.p
+        Wh = p["lstm_kernel"][(256 + self._action_size + 1) * 1024:]
+        h_prev = ws.h0 if t == 0 else ws.h[(t - 1) * B * 256:]
+        c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
+        g_t = ws.gates[t * B * 1024:]
+        ops.gemm(0, 0, B, 1024, 256, h_prev, 256, Wh, 1024, g_t, 1024, flags=ops.GEMM_ACCUM)
+        ops.lstm_gates_fwd(B, g_t, p["lstm_bias"], c_prev, g_t, ws.c[t * B * 256:], ws.h[t * B * 256:])
+
+    def features(self, ws, row0=0):
+        """(tensor, ld) of the features the heads read: LSTM outputs, or the fc output in FF mode."""
+        if self._use_lstm:
+            return ws.h[row0 * 256:], 256
+        return ws.xcat[row0 * XLD:], XLD
+
+    def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True):
+        """conv encoder -> fc -> (LSTM over T steps from ws.c0/ws.h0); rows = T*B listed in ws.frame_idx."""
+        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1)
+        if self._use_lstm:
+            for t in range(T):
+                self.lstm_step(ws, t, B)
+        return self.features(ws)
+
+    def trunk_backward(self, ring, ws, gws, T, B, d_feat, h0_nonzero=False):
+        """Back-propagate d_feat [T*B,256] through LSTM, fc and the conv encoder into self.g."""
+        p, g = self.p, self.g
+        rows = T * B
+        if self._use_lstm:
+            A = self._action_size
+            K_x = 256 + A + 1
+            W = p["lstm_kernel"]
+            Wh = W[K_x * 1024:]
+            gws.dc.zero_()
+            for t in reversed(range(T)):
+                c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
+                ops.lstm_gates_bwd(B, d_feat[t * B * 256:], gws.dh_rec if t < T - 1 else None, gws.dc,
+                                   ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:],
+                                   gws.d_gates[t * B * 1024:])
+                if t > 0:
+                    ops.gemm(0, 1, B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, Wh, 1024, gws.dh_rec, 256)
+            dW = g["lstm_kernel"]
+            ops.gemm(1, 0, K_x, 1024, rows, ws.xcat, XLD, gws.d_gates, 1024, dW, 1024,
+                     flags=ops.GEMM_ATOMIC, splitk=_splitk(K_x, 1024, rows))
+            if T > 1:
+                r1 = (T - 1) * B
+                ops.gemm(1, 0, 256, 1024, r1, ws.h, 256, gws.d_gates[B * 1024:], 1024, dW[K_x * 1024:], 1024,
+                         flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, r1))
+            if h0_nonzero:
+                ops.gemm(1, 0, 256, 1024, B, ws.h0, 256, gws.d_gates, 1024, dW[K_x * 1024:], 1024,
+                         flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, B))
+            ops.colsum(rows, 1024, gws.d_gates, 1024, g["lstm_bias"])
+            ops.gemm(0, 1, rows, 256, 1024, gws.d_gates, 1024, W, 1024, gws.d_fc, 256, mask=ws.xcat, ldm=XLD,
+                     flags=ops.GEMM_RELU_MASK)
+            d_fc = gws.d_fc
+        else:
+            ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, XLD)
+            d_fc = d_feat
+        ops.gemm(1, 0, 2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256, flags=ops.GEMM_ATOMIC,
+                 splitk=_splitk(2592, 256, rows))
+        ops.colsum(rows, 256, d_fc, 256, g["b_base_fc1"])
+        ops.gemm(0, 1, rows, 2592, 256, d_fc, 256, p["W_base_fc1"], 256, gws.d_f2, 2592, mask=ws.f2, ldm=2592,
+                 flags=ops.GEMM_RELU_MASK)
+        ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,
+                        g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
+
+    def heads_forward(self, rows, feat, ld, pi_out, v_out):
+        p, A = self.p, self._action_size
+        ops.linear_small_fwd(rows, 256, A, feat, ld, p["W_base_fc_p"], p["b_base_fc_p"], pi_out, A)
+        ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)
+
+    def value_forward(self, rows, feat, ld, v_out):
+        p = self.p
+        ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)
+
+    def pc_head_forward(self, rows, feat, ld, hp):
+        p = self.p
+        ops.gemm(0, 0, rows, 2592, 256, feat, ld, p["W_pc_fc1"], 2592, hp, 2592, bias=p["b_pc_fc1"],
+                 flags=ops.GEMM_RELU)
+
+    # -- reference batch-1 runners (model.py:630-728) ---------------------------------------------------
+    def _b1_ws(self):
+        if self._b1 is None:
+            dev = self._device
+            self._b1 = dict(ring=ops.Ring(3, 1, dev), ws=PathWS(3, 3, dev, save_c1=False, lstm=self._use_lstm),
+                            pi=torch.zeros(self._action_size, device=dev), v=torch.zeros(1, device=dev),
+                            hp=torch.zeros(2592, device=dev), q=torch.zeros(400, device=dev),
+                            z=torch.zeros(3, device=dev))
+        return self._b1
+
+    def _stage(self, images, last_action_reward=None):
+        """Quantise float images in [0,1] to the uint8 frame pool (frame_scale 1/255) of a scratch ring."""
+        b1 = self._b1_ws()
+        ring, ws = b1["ring"], b1["ws"]
+        n = len(images)
+        for k, img in enumerate(images):
+            a = np.asarray(img, dtype=np.float64)
+            u8 = np.clip(np.rint(a * 255.0), 0, 255).astype(np.uint8).reshape(-1)
+            ring.frames[k * ops.FRAME_BYTES:(k + 1) * ops.FRAME_BYTES].copy_(torch.from_numpy(u8))
+        ws.frame_idx[:n].copy_(torch.arange(n, dtype=torch.int32))
+        if last_action_reward is not None:
+            lar = np.asarray(last_action_reward, dtype=np.float32)
+            ring.r_last_action[0] = int(np.argmax(lar[:self._action_size]))
+            ring.r_last_reward[0] = float(lar[self._action_size])
+        return ring, ws
+
+    def _run_trunk1(self, s_t, last_action_reward, state):
+        ring, ws = self._stage([s_t['image']], last_action_reward)
+        scale = self.frame_scale
+        self.frame_scale = 1.0 / 255.0
+        try:
+            if self._use_lstm:
+                ws.c0[:256].copy_(state[0].reshape(-1))
+                ws.h0[:256].copy_(state[1].reshape(-1))
+            feat, ld = self.trunk_forward(ring, ws, 1, 1, lar_from_ring=True, save_c1=False)
+        finally:
+            self.frame_scale = scale
+        return ws, feat, ld
+
+    def run_base_policy_and_value(self, sess, s_t, last_action_reward, mode=""):
+        b1 = self._b1_ws()
+        ws, feat, ld = self._run_trunk1(s_t, last_action_reward, self.base_lstm_state_out)
+        self.heads_forward(1, feat, ld, b1["pi"], b1["v"])
+        ops.softmax_sample(1, self._action_size, b1["pi"], self._action_size)
+        if self._use_lstm:
+            self.base_lstm_state_out = (ws.c[:256].clone(), ws.h[:256].clone())
+        return b1["pi"].cpu().numpy(), float(b1["v"].cpu()[0]), None
+
+    def run_base_value(self, sess, s_t, last_action_reward):
+        b1 = self._b1_ws()
+        ws, feat, ld = self._run_trunk1(s_t, last_action_reward, self.base_lstm_state_out)   # state NOT advanced
+        self.value_forward(1, feat, ld, b1["v"])
+        return float(b1["v"].cpu()[0])
+
+    def _zero_state(self):
+        z = torch.zeros(256, dtype=torch.float32, device=self._device)
+        return (z, z)
+
+    def run_pc_q_max(self, sess, s_t, last_action_reward):
+        b1 = self._b1_ws()
+        ws, feat, ld = self._run_trunk1(s_t, last_action_reward, self._zero_state())
+        self.pc_head_forward(1, feat, ld, b1["hp"])
+        p = self.p
+        ops.pc_deconv_fwd(1, self._action_size, b1["hp"], p["W_pc_deconv_v"], p["b_pc_deconv_v"],
+                          p["W_pc_deconv_a"], p["b_pc_deconv_a"], qmax=b1["q"])
+        return b1["q"].cpu().numpy().reshape(20, 20)
+
+    def run_vr_value(self, sess, s_t, last_action_reward):
+        b1 = self._b1_ws()
+        ws, feat, ld = self._run_trunk1(s_t, last_action_reward, self._zero_state())
+        self.value_forward(1, feat, ld, b1["v"])
+        return float(b1["v"].cpu()[0])
+
+    def run_rp_c(self, sess, state_history):
+        b1 = self._b1_ws()
+        ring, ws = self._stage([s['image'] for s in state_history])
+        p = self.p
+        ops.encoder_fwd(ring.frames, ws.frame_idx[:3], 1.0 / 255.0, p["W_base_conv1"], p["b_base_conv1"],
+                        p["W_base_conv2"], p["b_base_conv2"], ws.f2, None)
+        ops.linear_small_fwd(1, 7776, 3, ws.f2, 7776, p["W_rp_fc1"], p["b_rp_fc1"], b1["z"], 3)
+        ops.softmax_sample(1, 3, b1["z"], 3)
+        return b1["z"].cpu().numpy()

@@ -32,8 +32,34 @@ def _chk(t, dt, n=None, name="tensor", optional=False):
         raise ValueError("%s: %d elements, need >= %d" % (name, t.numel(), n))
 
 
+_TIMER = None     # {"name", "events": [(start, end, units)]} while bench.py times one kernel with HIP events
+
+
 def _call(name, *a):
+    if _TIMER is not None and name == _TIMER["name"]:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib().call(name, *a, stream())
+        e1.record()
+        _TIMER["events"].append((e0, e1, a[0]))
+        return
     lib().call(name, *a, stream())
+
+
+def kernel_timer_start(name):
+    """Bracket every launch of kernel entry point `name` with HIP events on the launch stream."""
+    global _TIMER
+    _TIMER = {"name": name, "events": []}
+
+
+def kernel_timer_stop():
+    """-> {"launches", "ms" (sum of launch durations), "units" (sum of each launch's first size argument)}."""
+    global _TIMER
+    t, _TIMER = _TIMER, None
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in t["events"])
+    return {"name": t["name"], "launches": len(t["events"]), "ms": ms, "units": sum(u for _, _, u in t["events"])}
 
 
 # ---- environment ---------------------------------------------------------------------------------
@@ -166,6 +192,16 @@ def rollout_advance(B, terminal_t, active, active_log_t, n_steps, terminal_end):
 def seq_mask(B, T, seq_len, mask):
     _chk(seq_len, "i32", B); _chk(mask, "i32", B * T)
     _call("unreal_seq_mask", B, T, ptr(seq_len), ptr(mask))
+
+
+def seq_last_idx(B, seq_idx, seq_len, out):
+    _chk(seq_idx, "i32", 2 * B); _chk(seq_len, "i32", B); _chk(out, "i32", B)
+    _call("unreal_seq_last_idx", B, ptr(seq_idx), ptr(seq_len), ptr(out))
+
+
+def rollout_stats(B, n_steps, score_valid, score_out, stats):
+    _chk(n_steps, "i32", B); _chk(score_valid, "i32", B); _chk(score_out, "f32", B); _chk(stats, "f64", 3)
+    _call("unreal_rollout_stats", B, ptr(n_steps), ptr(score_valid), ptr(score_out), ptr(stats))
 
 
 def reset_state(B, terminal_end, c, h):

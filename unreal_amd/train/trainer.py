@@ -1,0 +1,386 @@
+"""Batched actor-learner: `Trainer.process()` for B maze actors per GPU on gfx950 kernels.
+
+Mirrors /root/reference/train/trainer.py: ctor 31-128, prepare 132-135, stop 137-138,
+_anneal_learning_rate 140-144, choose_action 147-148, set_start_time 172-173,
+_fill_experience 176-205, _process_base 218-336, _process_pc 339-380, _process_vr 383-412,
+_process_rp 415-436, process 438-636.
+
+What changes, and only this: the reference runs `parallel_size` Python threads, each
+rolling ONE environment with batch-1 session calls and applying its own clipped gradient to shared
+RMSProp slots.  Here ONE call advances all B actors of this GPU by <= n_step_TD steps in lock-step
+(an actor whose episode ends stops for the rest of the call, exactly like the reference's `break`),
+samples B pixel-control / value-replay / reward-prediction batches from the device ring, and makes
+one update with the MEAN over actors of the reference's per-actor gradient (sums over time), one
+global-norm clip and one RMSProp step.  With B == 1 this is the reference algorithm; staleness is 0.
+The rollout's activations are kept in HBM and reused by the backward pass (the reference recomputes
+the same forward with the same synced weights, trainer.py:457,543-570).
+
+Per-actor random draws come from a counter RNG (Philox) on the device; `draws` can be replaced to
+replay a recorded stream (parity tests).  TF-only arguments are accepted and ignored.
+"""
+import time
+
+import torch
+
+from .. import ops
+from ..environment.environment import Environment
+from ..environment.maze_environment import BatchedMazeEnvironment
+from ..model.model import UnrealModel, PathWS, GradWS
+from .experience import Experience
+
+PERFORMANCE_LOG_INTERVAL = 2000
+
+
+def log_uniform(lo, hi, rate):
+    """Initial learning rate (main.py:61-65): exp((1-rate) log lo + rate log hi) = 7.0711e-4 by default."""
+    import math
+    return math.exp(math.log(lo) * (1 - rate) + math.log(hi) * rate)
+
+
+class PhiloxDraws(object):
+    """Device draws; every call consumes a fresh Philox stream id (rank-disjoint)."""
+
+    def __init__(self, seed, rank=0):
+        self.seed = int(seed)
+        self.counter = (int(rank) << 40) + 1
+
+    def _next(self):
+        self.counter += 1
+        return self.counter
+
+    def uniform(self, out):
+        ops.philox_uniform(self.seed, self._next(), out)
+        return out
+
+    def randint(self, high, out):
+        ops.philox_randint(self.seed, self._next(), high, out)
+        return out
+
+
+class Trainer(object):
+    def __init__(self, thread_index, global_network, initial_learning_rate, learning_rate_input, grad_applier,
+                 env_type, env_name, use_lstm, use_pixel_change, use_value_replay, use_reward_prediction,
+                 pixel_change_lambda, entropy_beta, local_t_max, n_step_TD, gamma, gamma_pc,
+                 experience_history_size, max_global_time_step, device, segnet_param_dict=None,
+                 image_shape=(84, 84), is_training=True, n_classes=0, random_state=None, termination_time=50.0,
+                 segnet_lambda=1.0, dropout=0.0, batch_size=1, world_size=1, rank=0, seed=0xA3C, draws=None,
+                 grad_sync=None):
+        if env_type != "maze":
+            raise NotImplementedError("device actors exist for env_type='maze' only (SURVEY 8f: lab/indoor are next)")
+        self.thread_index = thread_index
+        self.learning_rate_input = learning_rate_input
+        self.env_type, self.env_name = env_type, env_name
+        self.use_lstm = use_lstm
+        self.use_pixel_change = use_pixel_change
+        self.use_value_replay = use_value_replay
+        self.use_reward_prediction = use_reward_prediction
+        self.pixel_change_lambda = pixel_change_lambda
+        self.entropy_beta = entropy_beta
+        self.local_t_max, self.n_step_TD = local_t_max, n_step_TD
+        self.gamma, self.gamma_pc = gamma, gamma_pc
+        self.experience_history_size = experience_history_size
+        self.max_global_time_step = max_global_time_step
+        self.action_size = Environment.get_action_size(env_type, env_name)
+        self.objective_size = Environment.get_objective_size(env_type, env_name)
+        self.device = torch.device(device if device not in (None, "/gpu:0", "/cpu:0") else "cuda:0")
+        self.B = int(batch_size)
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.grad_scale = 1.0 / float(self.B * self.world_size)
+        self.grad_sync = grad_sync
+        self.local_network = global_network          # one parameter copy per GPU (sync_from is a no-op)
+        self.grad_applier = grad_applier
+        self.apply_gradients = grad_applier.minimize_local(None, global_network.get_vars(),
+                                                           global_network.get_vars(), thread_index)
+        self.sync = self.local_network.sync_from(global_network)
+        self.initial_learning_rate = initial_learning_rate
+        self.draws = draws if draws is not None else PhiloxDraws(seed, rank)
+        self.local_t = 0
+        self.episode_reward = 0
+        self.prev_local_t = -1
+        self.start_time = time.time()
+        self.environment = None
+        self.experience = None
+        self.last_losses = {}
+        self.last_grad_norm = None
+
+    # ---------------------------------------------------------------------------------------------------
+    def prepare(self, termination_time=50.0, termination_dist_value=-10.0):
+        B, A, dev = self.B, self.action_size, self.device
+        T, Ta = self.n_step_TD, self.local_t_max
+        self.environment = BatchedMazeEnvironment(B, self.experience_history_size, dev)
+        self.ring = self.environment.ring
+        self.experience = Experience(self.experience_history_size, ring=self.ring)
+        lstm = self.use_lstm
+        aux = self.use_pixel_change or self.use_value_replay
+        self.base_ws = PathWS(T * B, B, dev, save_c1=True, lstm=lstm)
+        self.boot_ws = PathWS(B, B, dev, save_c1=False, lstm=lstm)
+        self.aux_ws = PathWS(Ta * B, B, dev, save_c1=True, lstm=lstm) if aux else None
+        self.rp_ws = PathWS(3 * B, B, dev, save_c1=True, lstm=False) if self.use_reward_prediction else None
+        rows = max(T, Ta if aux else 0, 3 if self.use_reward_prediction else 0) * B
+        self.gws = GradWS(rows, B, dev, lstm=lstm, pc=self.use_pixel_change, A=A)
+        f = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        i = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
+        d = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+        self.lstm_c, self.lstm_h = f(B * 256), f(B * 256)
+        self.pi, self.v = f(T * B * A), f(T * B)
+        self.actions, self.rewards, self.terminals = i(T * B), f(T * B), i(T * B)
+        self.active_log, self.active = i(T * B), i(B)
+        self.n_steps, self.terminal_end = i(B), i(B)
+        self.boot_v, self.R, self.adv = f(B), f(T * B), f(T * B)
+        self.dlogits, self.dv = f(max(T, Ta) * B * A), f(max(T, Ta) * B)
+        self.u_act = d(T * B)
+        self.losses = f(8)            # policy, value, entropy, pc, vr, rp
+        self.stats = d(3)
+        if aux:
+            L = Ta + 1
+            self.seq_idx, self.seq_len, self.seq_start = i(L * B), i(B), i(B)
+            self.seq_mask, self.seq_act = i(Ta * B), i(Ta * B)
+            self.aux_v, self.aux_R, self.aux_boot_v = f(Ta * B), f(Ta * B), f(B)
+            if self.use_pixel_change:
+                self.boot_hp, self.boot_qmax = f(B * ops.F2_DIM), f(B * ops.PC_CELLS)
+        if self.use_reward_prediction:
+            self.rp_coin, self.rp_u, self.rp_class = i(B), d(B), i(B)
+            self.rp_logits, self.rp_dlogits = f(B * 3), f(B * 3)
+        self._fill_calls = 0
+        self._full = False
+
+    def stop(self):
+        if self.environment is not None:
+            self.environment.stop()
+
+    def set_start_time(self, start_time):
+        self.start_time = start_time
+
+    def _anneal_learning_rate(self, global_time_step):
+        lr = self.initial_learning_rate * (self.max_global_time_step - global_time_step) / self.max_global_time_step
+        return max(lr, 0.0)
+
+    def choose_action(self, pi_values, u):
+        """Inverse-CDF draw (numpy RandomState.choice semantics) -- done on device by ops.softmax_sample."""
+        raise NotImplementedError("actions are drawn on the device; see ops.softmax_sample")
+
+    # ---------------------------------------------------------------------------------------------------
+    def _policy_step(self, ws, t, u, actions_out, pi_out, v_out):
+        """Forward the current observations of all actors as time row-block t of `ws` and draw actions."""
+        B, A, net = self.B, self.action_size, self.local_network
+        self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
+        net.encode_rows(self.ring, ws, t * B, B, lar_from_ring=False, save_c1=ws.c1 is not None)
+        if self.use_lstm:
+            net.lstm_step(ws, t, B)
+        feat, ld = net.features(ws, t * B)
+        net.heads_forward(B, feat, ld, pi_out, v_out)
+        ops.softmax_sample(B, A, pi_out, A, u, actions_out)
+
+    def _fill_experience(self, sess=None):
+        """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
+        B, ws = self.B, self.base_ws
+        if self.use_lstm:
+            ws.c0.copy_(self.lstm_c)
+            ws.h0.copy_(self.lstm_h)
+        self.draws.uniform(self.u_act[:B])
+        self._policy_step(ws, 0, self.u_act[:B], self.actions[:B], self.pi[:B * self.action_size], self.v[:B])
+        self.environment.process(self.actions[:B], None, self.rewards[:B], self.terminals[:B],
+                                 reset_on_terminal=True, track_score=False)
+        if self.use_lstm:                      # state advances; NOT reset on terminal here (:201-202)
+            self.lstm_c.copy_(ws.c[:B * 256])
+            self.lstm_h.copy_(ws.h[:B * 256])
+        self._fill_calls += 1
+        if self._fill_calls >= self.experience_history_size and self.experience.is_full():
+            self.environment.reset()           # trainer.py:203-205
+            self._full = True
+
+    def _rollout(self):
+        """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
+        B, T, A, ws, net = self.B, self.n_step_TD, self.action_size, self.base_ws, self.local_network
+        if self.use_lstm:
+            ws.c0.copy_(self.lstm_c)           # start_lstm_state
+            ws.h0.copy_(self.lstm_h)
+        self.active.fill_(1)
+        self.n_steps.zero_()
+        self.terminal_end.zero_()
+        self.draws.uniform(self.u_act)
+        for t in range(T):
+            s = slice(t * B, (t + 1) * B)
+            self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s])
+            self.environment.process(self.actions[s], self.active, self.rewards[s], self.terminals[s],
+                                     reset_on_terminal=True, track_score=True)
+            ops.rollout_advance(B, self.terminals[s], self.active, self.active_log[s], self.n_steps,
+                                self.terminal_end)
+        if self.use_lstm:
+            self.lstm_c.copy_(ws.c[(T - 1) * B * 256:T * B * 256])
+            self.lstm_h.copy_(ws.h[(T - 1) * B * 256:T * B * 256])
+        # bootstrap R = V(s_T) for actors still running; LSTM state NOT advanced (model.py:687-704)
+        bw = self.boot_ws
+        if self.use_lstm:
+            bw.c0.copy_(self.lstm_c)
+            bw.h0.copy_(self.lstm_h)
+        self.ring.cur_idx(out=bw.frame_idx[:B])
+        feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=False, save_c1=False)
+        net.value_forward(B, feat, ld, self.boot_v)
+        if self.use_lstm:                      # episode ended -> reset_state() (trainer.py:293)
+            ops.reset_state(B, self.terminal_end, self.lstm_c, self.lstm_h)
+        ops.base_returns(B, T, self.rewards, self.v, self.n_steps, self.boot_v, self.terminal_end, self.gamma,
+                         self.R, self.adv)
+
+    def _train_base(self):
+        B, T, A, ws, net, g, p = self.B, self.n_step_TD, self.action_size, self.base_ws, self.local_network, \
+            self.local_network.g, self.local_network.p
+        rows = T * B
+        ops.base_loss_grad(rows, A, self.pi, A, self.v, self.actions, self.adv, self.R, self.active_log,
+                           self.entropy_beta, self.grad_scale, self.dlogits, self.dv, self.losses[0:3])
+        feat, ld = net.features(ws)
+        d_feat = self.gws.d_feat
+        ops.linear_small_bwd(rows, 256, A, feat, ld, self.dlogits, A, p["W_base_fc_p"], d_feat, 256, False,
+                             g["W_base_fc_p"], g["b_base_fc_p"])
+        ops.linear_small_bwd(rows, 256, 1, feat, ld, self.dv, 1, p["W_base_fc_v"], d_feat, 256, True,
+                             g["W_base_fc_v"], g["b_base_fc_v"])
+        net.trunk_backward(self.ring, ws, self.gws, T, B, d_feat, h0_nonzero=True)
+
+    def _sample_sequence(self):
+        """experience.sample_sequence(local_t_max+1) for every actor + the bootstrap frame's features."""
+        B, Ta, net = self.B, self.local_t_max, self.local_network
+        L = Ta + 1
+        self.draws.randint(self.experience_history_size - L - 1, self.seq_start)
+        ops.replay_sample_seq(self.ring, L, self.seq_start, self.seq_idx, self.seq_len)
+        bw = self.boot_ws
+        ops.seq_last_idx(B, self.seq_idx, self.seq_len, bw.frame_idx[:B])
+        if self.use_lstm:
+            bw.c0.zero_()                      # aux networks always start from the zero state (model.py:395,461)
+            bw.h0.zero_()
+        feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=True, save_c1=False)
+        return feat, ld
+
+    def _aux_forward(self):
+        B, Ta, net, ws = self.B, self.local_t_max, self.local_network, self.aux_ws
+        rows = Ta * B
+        ws.frame_idx[:rows].copy_(self.seq_idx[:rows])
+        if self.use_lstm:
+            ws.c0.zero_()
+            ws.h0.zero_()
+        ops.seq_mask(B, Ta, self.seq_len, self.seq_mask)
+        return net.trunk_forward(self.ring, ws, Ta, B, lar_from_ring=True, save_c1=True)
+
+    def _train_pc(self):
+        """[Pixel change] (trainer.py:339-380, model.py:411-443, 542-557)."""
+        B, Ta, A, net = self.B, self.local_t_max, self.action_size, self.local_network
+        p, g, gws = net.p, net.g, self.gws
+        rows = Ta * B
+        feat, ld = self._sample_sequence()
+        net.pc_head_forward(B, feat, ld, self.boot_hp)
+        ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
+                          p["b_pc_deconv_a"], qmax=self.boot_qmax)
+        ops.pc_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.boot_qmax, self.gamma_pc, gws.pc_R)
+        feat, ld = self._aux_forward()
+        net.pc_head_forward(rows, feat, ld, gws.hp)
+        ops.gather_i32(self.ring.r_action, self.aux_ws.frame_idx[:rows], self.seq_act)
+        ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
+                          p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask,
+                          lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
+                          loss=self.losses[3:4])
+        d_hp = gws.d_f2
+        ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
+        from ..model.model import _splitk
+        ops.gemm(1, 0, 256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592, flags=ops.GEMM_ATOMIC,
+                 splitk=_splitk(256, 2592, rows))
+        ops.colsum(rows, 2592, d_hp, 2592, g["b_pc_fc1"])
+        ops.gemm(0, 1, rows, 256, 2592, d_hp, 2592, p["W_pc_fc1"], 2592, gws.d_feat, 256)
+        net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
+
+    def _train_vr(self):
+        """[Value replay] (trainer.py:383-412, model.py:446-470, 559-566)."""
+        B, Ta, net = self.B, self.local_t_max, self.local_network
+        p, g, gws = net.p, net.g, self.gws
+        rows = Ta * B
+        feat, ld = self._sample_sequence()
+        net.value_forward(B, feat, ld, self.aux_boot_v)
+        ops.vr_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.aux_boot_v, self.gamma, self.aux_R)
+        feat, ld = self._aux_forward()
+        net.value_forward(rows, feat, ld, self.aux_v)
+        ops.vr_loss_grad(rows, self.aux_v, self.aux_R, self.seq_mask, self.grad_scale, self.dv, self.losses[4:5])
+        ops.linear_small_bwd(rows, 256, 1, feat, ld, self.dv, 1, p["W_base_fc_v"], gws.d_feat, 256, False,
+                             g["W_base_fc_v"], g["b_base_fc_v"])
+        net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
+
+    def _train_rp(self):
+        """[Reward prediction] (trainer.py:415-436, model.py:473-488, 569-576)."""
+        B, net, ws = self.B, self.local_network, self.rp_ws
+        p, g, gws = net.p, net.g, self.gws
+        self.draws.randint(2, self.rp_coin)
+        self.draws.uniform(self.rp_u)
+        ops.replay_sample_rp(self.ring, self.rp_coin, self.rp_u, ws.frame_idx[:3 * B], self.rp_class)
+        ops.encoder_fwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv1"],
+                        p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1)
+        ops.linear_small_fwd(B, 7776, 3, ws.f2, 7776, p["W_rp_fc1"], p["b_rp_fc1"], self.rp_logits, 3)
+        ops.rp_loss_grad(B, self.rp_logits, self.rp_class, self.grad_scale, None, self.rp_dlogits,
+                         self.losses[5:6])
+        ops.linear_small_bwd(B, 7776, 3, ws.f2, 7776, self.rp_dlogits, 3, p["W_rp_fc1"], gws.d_f2, 7776, False,
+                             g["W_rp_fc1"], g["b_rp_fc1"])
+        ops.relu_mask(3 * B, 2592, gws.d_f2, 2592, ws.f2, 2592)
+        ops.encoder_bwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv2"], ws.c1,
+                        gws.d_f2, g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
+
+    # ---------------------------------------------------------------------------------------------------
+    def compute_gradients(self):
+        """Rollout + the four loss branches; leaves the local mean gradient in local_network.grads.flat."""
+        net = self.local_network
+        self._rollout()
+        net.grads.flat.zero_()
+        self.losses.zero_()
+        self._train_base()
+        if self.use_pixel_change:
+            self._train_pc()
+        if self.use_value_replay:
+            self._train_vr()
+        if self.use_reward_prediction:
+            self._train_rp()
+
+    def process(self, sess=None, global_t=0, summary_writer=None, summary_op_dict=None, score_input=None,
+                sr_input=None, eval_input=None, entropy_input=None, term_global_t=None, losses_input=None,
+                sync_stats=True):
+        """-> (env steps taken by this rank's actors inside the call, mean score of episodes finished or None)."""
+        if self.environment is None:
+            self.prepare()
+        if not self._full:
+            self._fill_experience(sess)
+            return 0, None
+        net = self.local_network
+        lr = self._anneal_learning_rate(global_t)
+        self.compute_gradients()
+        if self.grad_sync is not None:
+            self.grad_sync(net.grads.flat)               # RCCL all-reduce (sum of per-rank means / world)
+        self.last_grad_norm = self.grad_applier.step(net.params.flat, net.grads.flat, lr)
+        ops.rollout_stats(self.B, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
+        if not sync_stats:                               # stats keep accumulating on the device
+            return None, None
+        steps, episodes, score_sum = self.read_stats()
+        self._publish_losses()
+        return steps, (score_sum / episodes if episodes > 0 else None)
+
+    def read_stats(self):
+        """(env steps, finished episodes, sum of their scores) since the last read; one host sync."""
+        st = self.stats.cpu().numpy()
+        self.stats.zero_()
+        steps, episodes, score_sum = int(st[0]), int(st[1]), float(st[2])
+        self.local_t += steps
+        return steps, episodes, score_sum
+
+    def _publish_losses(self):
+        l = self.losses.cpu().numpy()
+        net = self.local_network
+        net.policy_loss, net.value_loss, net.entropy = float(l[0]), float(l[1]), float(l[2])
+        net.base_loss = net.policy_loss + net.value_loss
+        net.pc_loss, net.vr_loss, net.rp_loss = float(l[3]), float(l[4]), float(l[5])
+        net.total_loss = net.base_loss + net.pc_loss + net.vr_loss + net.rp_loss
+        self.last_losses = dict(total_loss=net.total_loss, base_loss=net.base_loss, policy_loss=net.policy_loss,
+                                value_loss=net.value_loss, entropy=net.entropy, pc_loss=net.pc_loss,
+                                vr_loss=net.vr_loss, rp_loss=net.rp_loss,
+                                grad_norm=float(self.last_grad_norm.cpu()[0]))
+        return self.last_losses
+
+    def _print_log(self, global_t):
+        if self.thread_index == 0 and self.local_t - self.prev_local_t >= PERFORMANCE_LOG_INTERVAL:
+            self.prev_local_t += PERFORMANCE_LOG_INTERVAL
+            el = time.time() - self.start_time
+            print("### Performance : {} STEPS in {:.0f} sec. {:.0f} STEPS/sec. {:.2f}M STEPS/hour".format(
+                global_t, el, global_t / el, global_t / el * 3600 / 1e6))
