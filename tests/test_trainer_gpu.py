@@ -115,7 +115,8 @@ def test_process_matches_oracle(use_lstm, aux):
         lr = tr._anneal_learning_rate(global_t)
         tr.compute_gradients()
         g_dev = {k: v.detach().cpu().double().numpy().copy() for k, v in net.g.items()}
-        norm_dev = float(applier.step(net.params.flat, net.grads.flat, lr).cpu()[0])
+        tr.last_grad_norm = applier.step(net.params.flat, net.grads.flat, lr)
+        norm_dev = float(tr.last_grad_norm.cpu()[0])
         tr.stats.zero_()
         from unreal_amd import ops
         ops.rollout_stats(B, tr.n_steps, tr.ring.score_valid, tr.ring.score_out, tr.stats)
