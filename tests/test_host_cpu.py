@@ -1,0 +1,121 @@
+"""CPU tests of the host logic and the C-ABI boundary (no GPU, no compute calls):
+  * libunreal_hip.so loads and exports every symbol include/unreal_hip.h declares
+  * the product path fails loudly without a GPU (no CPU fallback anywhere)
+  * flags keep the reference's names/defaults; parameter layout matches the reference's census
+  * learning-rate schedule, Philox stream bookkeeping."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from unreal_amd.build import build_library
+    return build_library(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built):
+    from unreal_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    dll = ctypes.CDLL(built)
+    for name, args in protos.items():
+        assert hasattr(dll, name), name
+        assert args[-1] is ctypes.c_void_p, "every entry point takes the stream last: %s" % name
+    L = _lib.lib()
+    assert set(L.protos) == set(protos)
+    # every exported unreal_* symbol is declared (no undocumented entry points)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built], stdout=subprocess.PIPE).stdout.decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T unreal_" in l}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_invalid_arguments_are_rejected_without_launch(built):
+    from unreal_amd import _lib
+    L = _lib.lib()
+    with pytest.raises(_lib.UnrealLibError):
+        L.call("unreal_gemm_f32", 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, None, 0, 0, 1, None)
+    with pytest.raises(_lib.UnrealLibError):
+        L.call("unreal_maze_step", 0, 3, *([None] * 18), 1, 0, None)
+    with pytest.raises(_lib.UnrealLibError):
+        L.call("unreal_rmsprop_step", None, None, None, None, 10, 0.1, 0.9, 0.0, 0.1, 40.0, None, None)
+
+
+def test_no_cpu_fallback():
+    from unreal_amd import ops
+    x = torch.zeros(16)
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        ops.colsum(4, 4, x, 4, torch.zeros(4))
+    with pytest.raises(ValueError, match="no CPU fallback"):
+        ops.gemm(0, 0, 4, 4, 4, x, 4, x, 4, x, 4)
+    if not torch.cuda.is_available():
+        from unreal_amd.model.model import UnrealModel
+        with pytest.raises(Exception):
+            UnrealModel(4, 0, -1, True, True, True, True, 0.05, 0.001, "cuda:0")
+
+
+def test_product_never_imports_the_oracle():
+    import re
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "unreal_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_options_keep_reference_names_and_defaults():
+    from unreal_amd.options import get_options
+    f = get_options("training")                       # options_lab.py preset
+    want = dict(use_lstm=True, use_pixel_change=True, use_value_replay=True, use_reward_prediction=True,
+                segnet=0, parallel_size=8, local_t_max=20, n_step_TD=20, entropy_beta=0.001, rmsp_alpha=0.99,
+                rmsp_epsilon=0.1, initial_alpha_low=1e-4, initial_alpha_high=5e-3, initial_alpha_log_rate=0.5,
+                gamma=0.99, gamma_pc=0.9, pixel_change_lambda=0.05, experience_history_size=2000,
+                max_time_step=13200000, save_interval_step=100000, grad_norm_clip=40.0, env_type="lab",
+                env_name="nav_maze_static_01", termination_time_sec=50.0, greedy_epsilon=0.99)
+    for k, v in want.items():
+        assert getattr(f, k) == v, k
+    d = get_options("training", preset="default")     # options.py
+    assert (d.use_pixel_change, d.segnet, d.n_step_TD, d.entropy_beta, d.n_classes, d.dropout) == \
+        (False, 2, 50, 0.0001, 19, 0.0)
+    g = get_options("training", argv=["--env_type", "maze", "--use_lstm", "False", "--unknown_flag", "1"])
+    assert g.env_type == "maze" and g.use_lstm is False
+    assert hasattr(get_options("display"), "frame_save_dir") and hasattr(get_options("evaluate"), "split")
+
+
+def test_param_layout_matches_reference_census():
+    from unreal_amd.model.model import param_spec, ALIGN
+    spec = param_spec(4)
+    assert len(spec) == 20 and sum(int(np.prod(s)) for _, s, _ in spec) == 1898877
+    assert len(param_spec(1, 0, True, True, False, False)) == 18      # model/model_test.py:14-58
+    assert len(param_spec(1, 0, True, False, True, False)) == 12
+    assert len(param_spec(1, 0, True, False, False, True)) == 14
+    assert sum(int(np.prod(s)) for _, s, _ in param_spec(4, 0, False, False, False, False)) == 676405
+    names = [n for n, _, _ in spec]
+    assert names[:8] == ["W_base_conv1", "b_base_conv1", "W_base_conv2", "b_base_conv2", "W_base_fc1",
+                         "b_base_fc1", "lstm_kernel", "lstm_bias"]
+    assert dict((n, s) for n, s, _ in spec)["lstm_kernel"] == (517, 1024)
+    off = 0
+    for _, shape, _ in spec:
+        assert off % ALIGN == 0
+        off += (int(np.prod(shape)) + ALIGN - 1) // ALIGN * ALIGN
+
+
+def test_learning_rate_schedule_and_draw_streams():
+    from unreal_amd.train.trainer import Trainer, PhiloxDraws, log_uniform
+    lr0 = log_uniform(1e-4, 5e-3, 0.5)
+    assert abs(lr0 - 7.0711e-4) < 1e-8
+    t = object.__new__(Trainer)
+    t.initial_learning_rate, t.max_global_time_step = lr0, 13200000
+    assert t._anneal_learning_rate(0) == lr0
+    assert abs(t._anneal_learning_rate(6600000) - lr0 / 2) < 1e-12
+    assert t._anneal_learning_rate(14000000) == 0.0
+    a, b = PhiloxDraws(1, rank=0), PhiloxDraws(1, rank=1)
+    sa = {a._next() for _ in range(1000)}
+    sb = {b._next() for _ in range(1000)}
+    assert not (sa & sb) and len(sa) == 1000
