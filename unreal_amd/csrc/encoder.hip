@@ -9,6 +9,9 @@
 // the LDS copy of W2.  Per group the uint8 frame (21 KB) and the conv1 activation (400 x 16 fp32,
 // row stride 20 floats so that ds_read_b128 im2col reads spread over the banks) live in LDS; the
 // frame is read from HBM exactly once, conv1 output never leaves the CU on the inference path.
+// Global traffic of frame n+1 is issued into registers while frame n is being computed and stored
+// to LDS one phase later, so HBM latency sits behind MFMA work; outputs leave through LDS-staged
+// 16 B/lane stores (full 128 B lines).
 // MFMA operand convention (16x16x4): lane l = (i = l&15, q = l>>4) supplies A[i][k] and B[k][i]
 // for ONE k per instruction; K is walked in a permuted order chosen so that one 32/128-bit LDS
 // read yields the operands of 4 consecutive MFMAs (k = f(chunk(q), s), s = 0..3).
@@ -22,6 +25,9 @@ constexpr int C1_LDS = C1_POS * C1_LD;   // 8000 floats
 constexpr int W2_ELEMS = 256 * 32;
 constexpr int D2_LD = 36;
 constexpr int D2_ROWS = 84;              // 81 + 3 zero rows (row 81 doubles as the "padding" row)
+constexpr int F2S = C2_POS * C2_CH;      // 2592 floats: conv2 output staging
+constexpr int FR_V = (FRAME_BYTES / 16 + 255) / 256;   // 16 B vectors per thread to move one frame (6)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void cvt4(uint32_t w, float (&f)[4]) {
   f[0] = (float)(w & 0xffu);
@@ -43,42 +49,51 @@ __device__ __forceinline__ void load_w1_regs(const float* __restrict__ W1, int q
     }
 }
 
-__device__ __forceinline__ void copy_frame_to_lds(const uint8_t* __restrict__ src, uint8_t* dst, int gtid) {
-  const uint4* s4 = reinterpret_cast<const uint4*>(src);
-  uint4* d4 = reinterpret_cast<uint4*>(dst);
-  for (int c = gtid; c < FRAME_BYTES / 16; c += 256) d4[c] = s4[c];
+__device__ __forceinline__ void frame_load(const uint8_t* __restrict__ src, int gtid, u32x4 (&r)[FR_V]) {
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+#pragma unroll
+  for (int c = 0; c < FR_V; ++c) {
+    int id = gtid + 256 * c;
+    r[c] = s4[id < FRAME_BYTES / 16 ? id : gtid];   // unconditional: keeps the array in registers
+  }
 }
 
-// conv1 for one group: fr (uint8 LDS) -> c1 (fp32 LDS, post-ReLU)
-__device__ __forceinline__ void conv1_tiles(const uint8_t* fr, float* c1, const float (&w1)[4][3][4], float bias_j,
-                                            float scale, int gw, int i, int q) {
-  for (int tt = gw; tt < 25; tt += 8) {
-    const int ta = tt, tb = min(tt + 4, 24);
-    const bool vb = (tt + 4) < 25;
-    const int pa = ta * 16 + i, pb = tb * 16 + i;
-    const int ba = (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
-    const int bb = (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
-    f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void frame_store(uint8_t* dst, int gtid, const u32x4 (&r)[FR_V]) {
+  u32x4* d4 = reinterpret_cast<u32x4*>(dst);
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+  for (int c = 0; c < FR_V; ++c) {
+    int id = gtid + 256 * c;
+    if (id < FRAME_BYTES / 16) d4[id] = r[c];
+  }
+}
+
+// conv1 for TWO (or one) 16-position tiles: fr (uint8 LDS) -> c1 (fp32 LDS, post-ReLU)
+template <bool TWO>
+__device__ __forceinline__ void conv1_tile_pair(const uint8_t* fr, float* c1, const float (&w1)[4][3][4], float bias_j,
+                                                float scale, int ta, int tb, int i, int q) {
+  const int pa = ta * 16 + i, pb = tb * 16 + i;
+  const int ba = (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
+  const int bb = (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
+  f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int cc = 3 * q + c;
-        const int off = (2 * p + cc / 6) * FRAME_ROW_BYTES + 4 * (cc % 6);
-        float fa[4], fb[4];
-        cvt4(*reinterpret_cast<const uint32_t*>(fr + ba + off), fa);
-        cvt4(*reinterpret_cast<const uint32_t*>(fr + bb + off), fb);
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acca = MFMA16(fa[s], w1[p][c][s], acca);
-          accb = MFMA16(fb[s], w1[p][c][s], accb);
-        }
+    for (int c = 0; c < 3; ++c) {
+      const int cc = 3 * q + c;
+      const int off = (2 * p + cc / 6) * FRAME_ROW_BYTES + 4 * (cc % 6);
+      float fa[4], fb[4];
+      cvt4(*reinterpret_cast<const uint32_t*>(fr + ba + off), fa);
+      if (TWO) cvt4(*reinterpret_cast<const uint32_t*>(fr + bb + off), fb);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acca = MFMA16(fa[s], w1[p][c][s], acca);
+        if (TWO) accb = MFMA16(fb[s], w1[p][c][s], accb);
       }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      c1[(ta * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * acca[r] + bias_j, 0.f);
-      if (vb) c1[(tb * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * accb[r] + bias_j, 0.f);
     }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    c1[(ta * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * acca[r] + bias_j, 0.f);
+    if (TWO) c1[(tb * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * accb[r] + bias_j, 0.f);
   }
 }
 
@@ -87,13 +102,15 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
                                                           const float* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ W2, const float* __restrict__ b2,
                                                           float* __restrict__ c1_out, float* __restrict__ f2_out) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (FR_LDS + C1_LDS * 4) + W2_ELEMS * 4];
+  constexpr int GRP_BYTES = FR_LDS + C1_LDS * 4 + F2S * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + W2_ELEMS * 4];
   const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  uint8_t* fr = smem + grp * (FR_LDS + C1_LDS * 4);
+  uint8_t* fr = smem + grp * GRP_BYTES;
   float* c1 = reinterpret_cast<float*>(fr + FR_LDS);
-  float* w2s = reinterpret_cast<float*>(smem + 2 * (FR_LDS + C1_LDS * 4));
+  float* f2s = c1 + C1_LDS;
+  float* w2s = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
 
   // W2 -> LDS as [(ky*4+c)][q][n(32)][s]: k = ky*64 + q*16 + 4c + s
   for (int e = threadIdx.x; e < W2_ELEMS; e += 512) {
@@ -108,27 +125,36 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
   const float bias2 = b2[nt * 16 + i];
 
   const int stride = gridDim.x * 2;
-  int n = blockIdx.x * 2 + grp;
-  if (n < N) copy_frame_to_lds(frames + (size_t)frame_idx[n] * FRAME_BYTES, fr, gtid);
+  u32x4 pre[FR_V];
+  {
+    const int n0 = blockIdx.x * 2 + grp;
+    if (n0 < N) {
+      frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, gtid, pre);
+      frame_store(fr, gtid, pre);
+    }
+  }
   __syncthreads();
 
+  int prev = -1;                               // frame whose conv2 output still sits in f2s
   for (int base = blockIdx.x * 2; base < N; base += stride) {
-    n = base + grp;
+    const int n = base + grp;
     const bool valid = n < N;
-    if (valid) conv1_tiles(fr, c1, w1, bias1, scale, gw, i, q);
-    __syncthreads();  // c1 complete; fr free
-
-    const int nn = n + stride;
-    uint4 pre[6];
-    const bool has_next = nn < N;
-    if (has_next) {
-      const uint4* s4 = reinterpret_cast<const uint4*>(frames + (size_t)frame_idx[nn] * FRAME_BYTES);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        int id = gtid + 256 * c;
-        if (id < FRAME_BYTES / 16) pre[c] = s4[id];
+    // drain the previous frame's conv2 output: LDS -> HBM in full 128 B lines
+    if (prev >= 0) {
+      f32x4* dst = reinterpret_cast<f32x4*>(f2_out + (size_t)prev * F2_DIM);
+      for (int id = gtid; id < F2S / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(f2s)[id];
+    }
+    if (valid) {
+      for (int tt = gw; tt < 25; tt += 8) {
+        if (tt + 4 < 25) conv1_tile_pair<true>(fr, c1, w1, bias1, scale, tt, tt + 4, i, q);
+        else conv1_tile_pair<false>(fr, c1, w1, bias1, scale, tt, tt, i, q);
       }
     }
+    __syncthreads();  // c1 complete; fr free; f2s drained
+
+    const int nn = n + stride;
+    const bool has_next = nn < N;
+    if (has_next) frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, gtid, pre);
 
     if (valid) {
       // conv2: this wave owns M-tiles mt = (gw>>1) + 2*jj (jj = 0..2) of N-tile nt
@@ -154,13 +180,12 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) acc[jj] = MFMA16(av[jj][s], bw[s], acc[jj]);
         }
-      float* f2 = f2_out + (size_t)n * F2_DIM;
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           int pos2 = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
-          if (pos2 < C2_POS) f2[pos2 * 32 + nt * 16 + i] = fmaxf(acc[jj][r] + bias2, 0.f);
+          if (pos2 < C2_POS) f2s[pos2 * 32 + nt * 16 + i] = fmaxf(acc[jj][r] + bias2, 0.f);
         }
       if (c1_out) {
         f32x4* dst = reinterpret_cast<f32x4*>(c1_out + (size_t)n * (C1_POS * C1_CH));
@@ -168,15 +193,13 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
           dst[id] = *reinterpret_cast<const f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4);
       }
     }
-    if (has_next) {
-      uint4* d4 = reinterpret_cast<uint4*>(fr);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        int id = gtid + 256 * c;
-        if (id < FRAME_BYTES / 16) d4[id] = pre[c];
-      }
-    }
-    __syncthreads();  // next frame staged; c1 free
+    if (has_next) frame_store(fr, gtid, pre);
+    prev = valid ? n : -1;
+    __syncthreads();  // next frame staged; c1 free; f2s complete
+  }
+  if (prev >= 0) {
+    f32x4* dst = reinterpret_cast<f32x4*>(f2_out + (size_t)prev * F2_DIM);
+    for (int id = gtid; id < F2S / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(f2s)[id];
   }
 }
 
@@ -188,7 +211,78 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
 //   (2) d1[2a+pa][2b+pb][c] = sum_{da,db,n} d2[a-da][b-db][n] * W2[pa+2da][pb+2db][c][n]
 //       per output parity (pa,pb): M=100 N=16 K=128; masked by c1 > 0 and written in place of c1
 //   (3) dW1[(ky,kx,cin)][c] += scale * sum_pos u8[4oy+ky][4ox+kx][cin] * d1[pos][c]  M=192 N=16 K=400
+// Pipeline per frame: the NEXT frame's uint8 image, c1 and d2 are fetched into registers while phase (3)
+// of the current frame runs and are stored to LDS right after it.
 // ------------------------------------------------------------------------------------------------
+constexpr int C1_V = (C1_POS * 4 + 255) / 256;   // f32x4 per thread for one c1 image (7)
+constexpr int D2_V = (C2_POS * 8 + 255) / 256;   // f32x4 per thread for one d2 image (3)
+
+// conv2 dgrad for NT output tiles (16 positions each) of ONE output parity: one weight fragment read
+// (w2t, LDS) feeds all NT tiles.
+template <int NT>
+__device__ __forceinline__ float dgrad_tiles(const float* d2, float* c1, const float* w2t, int par, int mt0, int i,
+                                             int q) {
+  f32x4 acc[NT];
+  int a[NT], b[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m = min((mt0 + t) * 16 + i, 99);
+    a[t] = m / 10;
+    b[t] = m % 10;
+  }
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const int da = dd >> 1, db = dd & 1;
+    int row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int y = a[t] - da, x = b[t] - db;
+      row[t] = ((y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS) * D2_LD + 4 * q;
+    }
+#pragma unroll
+    for (int cch = 0; cch < 2; ++cch) {
+      f32x4 av[NT];
+      const f32x4 bw = *reinterpret_cast<const f32x4*>(w2t + ((((par * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const f32x4*>(d2 + row[t] + 16 * cch);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA16(av[t][s], bw[s], acc[t]);
+    }
+  }
+  float db1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (mt0 + t) * 16 + 4 * q + r;
+      if (m < 100) {
+        const int idx = ((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * C1_LD + i;
+        const float g = c1[idx] > 0.f ? acc[t][r] : 0.f;
+        c1[idx] = g;
+        db1 += g;
+      }
+    }
+  return db1;
+}
+
+#ifdef UNREAL_ABLATE
+__device__ unsigned long long g_stamp_sum[16];
+#define STAMP(k)                                                                   \
+  do {                                                                             \
+    if (PHASES == 7 && blockIdx.x == 3 && threadIdx.x == 0) {                      \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+      g_stamp_sum[k] += t_ - t_prev_;                                              \
+      t_prev_ = t_;                                                                \
+    }                                                                              \
+  } while (0)
+#else
+#define STAMP(k)
+#endif
+
+template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
 __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
                                                           const int* __restrict__ frame_idx, float scale,
                                                           const float* __restrict__ W2,
@@ -205,7 +299,6 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
   float* c1 = reinterpret_cast<float*>(fr + FR_LDS);
   float* d2 = c1 + C1_LDS;
   float* w2t = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
-
   // W2 for dgrad as [par(4)][dd(4)][cch(2)][q(4)][c(16)][s(4)]:
   //   value W2[((pa+2da)*4 + (pb+2db))*16 + c][n], n = 16cch + 4q + s
   for (int e = threadIdx.x; e < W2_ELEMS; e += 512) {
@@ -234,16 +327,18 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
   }
 
   const int stride = gridDim.x * 2;
-  for (int base = blockIdx.x * 2; base < N; base += stride) {
-    const int n = base + grp;
-    const bool valid = n < N;
-    __syncthreads();  // previous frame fully consumed
-    if (valid) {
-      copy_frame_to_lds(frames + (size_t)frame_idx[n] * FRAME_BYTES, fr, gtid);
-      const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n * (C1_POS * C1_CH));
+  f32x4 pc1[C1_V], pd2[D2_V];
+  u32x4 pfr[FR_V];
+  // prologue: stage c1 / d2 of this group's first frame
+  {
+    const int n0 = blockIdx.x * 2 + grp;
+    if (n0 < N) {
+      frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, gtid, pfr);
+      frame_store(fr, gtid, pfr);
+      const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n0 * (C1_POS * C1_CH));
       for (int id = gtid; id < C1_POS * 4; id += 256)
         *reinterpret_cast<f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4) = cs[id];
-      const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)n * F2_DIM);
+      const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)n0 * F2_DIM);
       for (int id = gtid; id < C2_POS * 8; id += 256) {
         f32x4 v = ds[id];
         *reinterpret_cast<f32x4*>(d2 + (id >> 3) * D2_LD + (id & 7) * 4) = v;
@@ -251,83 +346,143 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
         for (int e = 0; e < 4; ++e) adb2[e] += v[e];
       }
     }
-    __syncthreads();
+  }
 
-    if (valid) {
-      // (1) conv2 wgrad
-      for (int st = 0; st < 21; ++st) {
-        const int kp = min(4 * st + q, C2_POS - 1);
-        const int kpb = 4 * st + q;                       // rows 81..83 of d2 are zero
-        const int ab = ((2 * (kp / 9) + gw) * 20 + 2 * (kp % 9)) * C1_LD + i;
-        const float b0 = d2[kpb * D2_LD + i], b1v = d2[kpb * D2_LD + 16 + i];
+#ifdef UNREAL_ABLATE
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (int base = blockIdx.x * 2; base < N; base += stride) {
+    const int n = base + grp;
+    const bool valid = n < N;
+    const int nn = n + stride;
+    const bool has_next = nn < N;
+    STAMP(8);
+    __syncthreads();  // [S0] c1 / d2 of frame n staged
+    STAMP(0);
+    if (valid && (PHASES & 1)) {
+      // (1) conv2 wgrad; operands of step st+1 are read from LDS before the MFMAs of step st issue.
+      // The step loop is kept rolled (3 steps per trip): fully unrolled, the 21 lane-dependent address sets are
+      // loop-invariant across frames, get hoisted and spill.
+      float av[4], bv0, bv1;
+      {
+        const int ab = (gw * 20) * C1_LD + i + q * 2 * C1_LD;          // kp = q < 9
+        bv0 = d2[q * D2_LD + i]; bv1 = d2[q * D2_LD + 16 + i];
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const float av = c1[ab + kx * C1_LD];
-          aw2[kx][0] = MFMA16(av, b0, aw2[kx][0]);
-          aw2[kx][1] = MFMA16(av, b1v, aw2[kx][1]);
+        for (int kx = 0; kx < 4; ++kx) av[kx] = c1[ab + kx * C1_LD];
+      }
+#pragma unroll 1
+      for (int sb = 0; sb < 21; sb += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int st = sb + u;
+          float an[4], bn0, bn1;
+          {
+            const int kpb = min(4 * (st + 1) + q, D2_ROWS - 1);   // rows 81..83 of d2 are zero; st = 20 reads a dummy
+            const int kp = min(kpb, C2_POS - 1);
+            const int ab = ((2 * (kp / 9) + gw) * 20 + 2 * (kp % 9)) * C1_LD + i;
+            bn0 = d2[kpb * D2_LD + i]; bn1 = d2[kpb * D2_LD + 16 + i];
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) an[kx] = c1[ab + kx * C1_LD];
+          }
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) {
+            aw2[kx][0] = MFMA16(av[kx], bv0, aw2[kx][0]);
+            aw2[kx][1] = MFMA16(av[kx], bv1, aw2[kx][1]);
+          }
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) av[kx] = an[kx];
+          bv0 = bn0; bv1 = bn1;
         }
       }
     }
-    __syncthreads();  // all reads of c1 done before the in-place dgrad overwrite
+    STAMP(1);
+    __syncthreads();  // [S1] all reads of c1 done before the in-place dgrad overwrite
+    STAMP(2);
 
-    if (valid) {
-      // (2) conv2 dgrad, 28 jobs (par, mt) over 4 waves, two at a time
-      for (int jb = gw; jb < 28; jb += 8) {
-        const int j0 = jb, j1 = min(jb + 4, 27);
-        const bool v1 = (jb + 4) < 28;
-        const int par0 = j0 / 7, mt0 = j0 % 7, par1 = j1 / 7, mt1 = j1 % 7;
-        const int m0 = min(mt0 * 16 + i, 99), m1 = min(mt1 * 16 + i, 99);
-        const int a0 = m0 / 10, bb0 = m0 % 10, a1 = m1 / 10, bb1 = m1 % 10;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (valid && (PHASES & 2)) {
+      // (2) conv2 dgrad: wave gw owns output parity gw; its 7 position tiles as 4 + 3 independent accumulators
+      adb1 += dgrad_tiles<4>(d2, c1, w2t, gw, 0, i, q);
+      adb1 += dgrad_tiles<3>(d2, c1, w2t, gw, 4, i, q);
+    }
+    STAMP(3);
+    __syncthreads();  // [S2] c1 holds d1; frame staged; d2 free
+    STAMP(4);
+
+    if (has_next) {   // fetch the next frame's uint8 image, c1 and d2 behind phase (3)
+      frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, gtid, pfr);
+      const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)nn * (C1_POS * C1_CH));
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          const int da = dd >> 1, db = dd & 1;
-          const int y0 = a0 - da, x0 = bb0 - db, y1 = a1 - da, x1 = bb1 - db;
-          const int r0 = (y0 >= 0 && y0 < 9 && x0 >= 0 && x0 < 9) ? y0 * 9 + x0 : C2_POS;
-          const int r1 = (y1 >= 0 && y1 < 9 && x1 >= 0 && x1 < 9) ? y1 * 9 + x1 : C2_POS;
+      for (int c = 0; c < C1_V; ++c) {
+        int id = gtid + 256 * c;
+        pc1[c] = cs[id < C1_POS * 4 ? id : gtid];
+      }
+      const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)nn * F2_DIM);
 #pragma unroll
-          for (int cch = 0; cch < 2; ++cch) {
-            const f32x4 av0 = *reinterpret_cast<const f32x4*>(d2 + r0 * D2_LD + 16 * cch + 4 * q);
-            const f32x4 av1 = *reinterpret_cast<const f32x4*>(d2 + r1 * D2_LD + 16 * cch + 4 * q);
-            const f32x4 bw0 = *reinterpret_cast<const f32x4*>(w2t + ((((par0 * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
-            const f32x4 bw1 = *reinterpret_cast<const f32x4*>(w2t + ((((par1 * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
+      for (int c = 0; c < D2_V; ++c) {
+        int id = gtid + 256 * c;
+        pd2[c] = ds[id < C2_POS * 8 ? id : gtid];
+      }
+    }
+    if (valid && (PHASES & 4)) {
+      // (3) conv1 wgrad.  Positions kp = 20*sy + 4*s5 + q: all addresses are linear in (sy, s5) -> immediates +
+      // one add per row.  One row of operands (5 steps) is read ahead of the row being multiplied.
+      const uint8_t* fa0 = fr + 12 * q + off1[0];
+      const uint8_t* fa1 = fr + 12 * q + off1[1];
+      const uint8_t* fa2 = fr + 12 * q + off1[2];
+      const float* dp = c1 + q * C1_LD + i;
+      float bc[5], ac[5][3];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              acc0 = MFMA16(av0[s], bw0[s], acc0);
-              acc1 = MFMA16(av1[s], bw1[s], acc1);
-            }
+      for (int s5 = 0; s5 < 5; ++s5) {
+        bc[s5] = dp[4 * s5 * C1_LD];
+        ac[s5][0] = (float)fa0[48 * s5]; ac[s5][1] = (float)fa1[48 * s5]; ac[s5][2] = (float)fa2[48 * s5];
+      }
+      for (int sy = 0; sy < 20; ++sy) {
+        fa0 += 4 * FRAME_ROW_BYTES; fa1 += 4 * FRAME_ROW_BYTES; fa2 += 4 * FRAME_ROW_BYTES;
+        dp += 20 * C1_LD;
+        float bn[5], an[5][3];
+        if (sy + 1 < 20) {
+#pragma unroll
+          for (int s5 = 0; s5 < 5; ++s5) {
+            bn[s5] = dp[4 * s5 * C1_LD];
+            an[s5][0] = (float)fa0[48 * s5]; an[s5][1] = (float)fa1[48 * s5]; an[s5][2] = (float)fa2[48 * s5];
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int m = mt0 * 16 + 4 * q + r;
-          if (m < 100) {
-            int idx = ((2 * (m / 10) + (par0 >> 1)) * 20 + 2 * (m % 10) + (par0 & 1)) * C1_LD + i;
-            float g = c1[idx] > 0.f ? acc0[r] : 0.f;
-            c1[idx] = g;
-            adb1 += g;
-          }
-          m = mt1 * 16 + 4 * q + r;
-          if (v1 && m < 100) {
-            int idx = ((2 * (m / 10) + (par1 >> 1)) * 20 + 2 * (m % 10) + (par1 & 1)) * C1_LD + i;
-            float g = c1[idx] > 0.f ? acc1[r] : 0.f;
-            c1[idx] = g;
-            adb1 += g;
+        for (int s5 = 0; s5 < 5; ++s5) {
+          aw1[0] = MFMA16(ac[s5][0], bc[s5], aw1[0]);
+          aw1[1] = MFMA16(ac[s5][1], bc[s5], aw1[1]);
+          aw1[2] = MFMA16(ac[s5][2], bc[s5], aw1[2]);
+        }
+        if (sy + 1 < 20) {
+#pragma unroll
+          for (int s5 = 0; s5 < 5; ++s5) {
+            bc[s5] = bn[s5];
+            ac[s5][0] = an[s5][0]; ac[s5][1] = an[s5][1]; ac[s5][2] = an[s5][2];
           }
         }
       }
     }
-    __syncthreads();  // c1 now holds d1
-
-    if (valid) {
-      // (3) conv1 wgrad
-      for (int st = 0; st < 100; ++st) {
-        const int kp = 4 * st + q;
-        const int fb = (4 * (kp / 20)) * FRAME_ROW_BYTES + 12 * (kp % 20);
-        const float bv = c1[kp * C1_LD + i];
+    if (has_next) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) aw1[a] = MFMA16((float)fr[fb + off1[a]], bv, aw1[a]);
+      for (int c = 0; c < D2_V; ++c) {
+        int id = gtid + 256 * c;
+        if (id < C2_POS * 8) {
+          *reinterpret_cast<f32x4*>(d2 + (id >> 3) * D2_LD + (id & 7) * 4) = pd2[c];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) adb2[e] += pd2[c][e];
+        }
       }
+    }
+    STAMP(5);
+    __syncthreads();  // [S3] phase (3) finished reading c1 (d1)
+    STAMP(6);
+    if (has_next) {
+#pragma unroll
+      for (int c = 0; c < C1_V; ++c) {
+        int id = gtid + 256 * c;
+        if (id < C1_POS * 4) *reinterpret_cast<f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4) = pc1[c];
+      }
+      frame_store(fr, gtid, pfr);
     }
   }
 
@@ -378,9 +533,36 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
   if (N <= 0 || !frames || !frame_idx || !W2 || !c1_saved || !d2 || !dW1 || !db1 || !dW2 || !db2)
     return UNREAL_EINVAL;
   int blocks = min((N + 1) / 2, 256);
-  hipLaunchKernelGGL(encoder_bwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, frame_idx,
+  hipLaunchKernelGGL(encoder_bwd_kernel<7>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, frame_idx,
                      frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2);
   return unreal_launch_status();
 }
+
+#ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
+int exp_read_stamps(unsigned long long* host16, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_stamp_sum), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z));
+  }
+  return 0;
+}
+int exp_encoder_bwd_phases(int phases, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
+                           const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
+                           float* db2, void* stream) {
+  int blocks = min((N + 1) / 2, 256);
+#define LAUNCH_(P) hipLaunchKernelGGL(encoder_bwd_kernel<P>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, \
+                                      frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2)
+  switch (phases) {
+    case 0: LAUNCH_(0); break;
+    case 1: LAUNCH_(1); break;
+    case 2: LAUNCH_(2); break;
+    case 4: LAUNCH_(4); break;
+    default: LAUNCH_(7); break;
+  }
+  return unreal_launch_status();
+}
+#endif
 
 }  // extern "C"

@@ -164,29 +164,69 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool first_split = blockIdx.z == 0;
+  if (p.flags & FLAG_ATOMIC) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+        if (col >= p.N) continue;
+        const float bv = (p.bias && first_split) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+          if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r] + bv);
+        }
+      }
+    return;
+  }
+  // stage the tile through LDS so every lane moves 16 B of one row: full 128 B lines for C, mask and accumulate
+  constexpr int CLD = BN + 4;
+  static_assert(BM * CLD <= 2 * (A_ELEMS + B_ELEMS), "C tile must fit in the operand LDS");
+  float* Cs = smem;     // operand buffers are dead: the K loop ended with a barrier
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * (BN / 2) + j * 32 + li;
-      if (col >= p.N) continue;
-      const float bv = (p.bias && first_split) ? p.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        float* cp = p.C + (size_t)row * p.ldc + col;
-        if (p.flags & FLAG_ATOMIC) {
-          atomicAdd(cp, v);
-        } else {
-          if (p.flags & FLAG_ACCUM) v += *cp;
-          if (p.flags & FLAG_RELU) v = fmaxf(v, 0.f);
-          if (p.flags & FLAG_RELU_MASK) v = (p.mask[(size_t)row * p.ldm + col] > 0.f) ? v : 0.f;
-          *cp = v;
-        }
+      for (int r = 0; r < 16; ++r)
+        Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
+  __syncthreads();
+  const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
+                    (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
+                    (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
+  constexpr int CV = BN / 4;                      // f32x4 per tile row
+  for (int id = threadIdx.x; id < BM * CV; id += 256) {
+    const int r = id / CV, c4 = (id % CV) * 4;
+    const int row = m0 + r, col = n0 + c4;
+    if (row >= p.M || col >= p.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+    float* cp = p.C + (size_t)row * p.ldc + col;
+    if (vecC && col + 3 < p.N) {
+      if (p.bias) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col); v += b4; }
+      if (p.flags & FLAG_ACCUM) v += *reinterpret_cast<const f32x4*>(cp);
+      if (p.flags & FLAG_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.flags & FLAG_RELU_MASK) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.ldm + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m4[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(cp) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (col + e >= p.N) break;
+        float x = v[e] + (p.bias ? p.bias[col + e] : 0.f);
+        if (p.flags & FLAG_ACCUM) x += cp[e];
+        if (p.flags & FLAG_RELU) x = fmaxf(x, 0.f);
+        if (p.flags & FLAG_RELU_MASK) x = (p.mask[(size_t)row * p.ldm + col + e] > 0.f) ? x : 0.f;
+        cp[e] = x;
       }
     }
+  }
 }
 
 template <int BM, int BN>
