@@ -97,9 +97,11 @@ int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, 
 /* ---- heads, sampling, losses (model/model.py:358-377, 473-516, 559-576; train/trainer.py:147-148) -- */
 int unreal_linear_small_fwd(int rows, int K, int NOUT, const float* X, int ldx, const float* W, const float* b,
                             float* out, int ldo, void* stream);
+/* dX (nullable) (+)= dO W^T; dW[k*dw_stride_k + n*dw_stride_n] += sum_rows X[row][k] dO[row][n]
+ * (strides 0,0 = the natural [K][NOUT] layout; W may be null when dX is null); db (nullable) += sum_rows dO */
 int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, const float* dO, int ldo,
-                            const float* W, float* dX, int lddx, int accumulate_dx, float* dW, float* db,
-                            void* stream);
+                            const float* W, float* dX, int lddx, int accumulate_dx, float* dW, int dw_stride_k,
+                            int dw_stride_n, float* db, void* stream);
 int unreal_softmax_sample(int rows, int A, float* logits_pi, int ld, const double* u, int* action, void* stream);
 int unreal_base_loss_grad(int rows, int A, const float* pi, int ld_pi, const float* v, const int* action,
                           const float* adv, const float* R, const int* active, float entropy_beta, float grad_scale,

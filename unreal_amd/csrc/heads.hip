@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
                                                                const float* __restrict__ dO, int ldo,
                                                                const float* __restrict__ W, float* __restrict__ dX,
                                                                int lddx, int accumulate_dx, float* __restrict__ dW,
-                                                               float* __restrict__ db) {
+                                                               int dw_sk, int dw_sn, float* __restrict__ db) {
   extern __shared__ float sdo[];   // [rows_per_block][NOUT]
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * rows_per_block;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
   if (k >= K) return;
   float w[NOUT], acc[NOUT];
 #pragma unroll
-  for (int n = 0; n < NOUT; ++n) { w[n] = W[(size_t)k * NOUT + n]; acc[n] = 0.f; }
+  for (int n = 0; n < NOUT; ++n) { w[n] = W ? W[(size_t)k * NOUT + n] : 0.f; acc[n] = 0.f; }
   for (int r = 0; r < nr; ++r) {
     const size_t row = (size_t)(r0 + r);
     float xv = X[row * ldx + k];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
     }
   }
 #pragma unroll
-  for (int n = 0; n < NOUT; ++n) atomicAdd(dW + (size_t)k * NOUT + n, acc[n]);
+  for (int n = 0; n < NOUT; ++n) atomicAdd(dW + (size_t)k * dw_sk + (size_t)n * dw_sn, acc[n]);
   if (db && blockIdx.x == 0 && threadIdx.x < NOUT) {
     float s = 0.f;
     for (int r = 0; r < nr; ++r) s += sdo[r * NOUT + threadIdx.x];
@@ -230,15 +230,27 @@ __global__ __launch_bounds__(256) void rp_loss_grad_kernel(int rows, const float
   if ((threadIdx.x & 63) == 0) atomicAdd(loss, l * grad_scale);
 }
 
-// out[c] += sum_r X[r][c]; block = 256 columns x chunk of rows
+// out[c] += sum_r X[r][c]; block = 64 columns x 4 row phases over a chunk of rows, one atomic per column
 __global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, int rows_per_block, const float* __restrict__ X,
                                                      int ld, float* __restrict__ out) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + c];
-  atomicAdd(out + c, s);
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      s0 += X[(size_t)r * ld + c];
+      s1 += X[(size_t)(r + 4) * ld + c];
+      s2 += X[(size_t)(r + 8) * ld + c];
+      s3 += X[(size_t)(r + 12) * ld + c];
+    }
+    for (; r < r1; r += 4) s0 += X[(size_t)r * ld + c];
+  }
+  part[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && c < cols) atomicAdd(out + c, (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
 }
 
 // d[r][c] = src[r][c] > 0 ? d[r][c] : 0
@@ -260,11 +272,12 @@ int launch_small_fwd(int rows, int K, const float* X, int ldx, const float* W, c
 
 template <int NOUT>
 int launch_small_bwd(int rows, int K, const float* X, int ldx, const float* dO, int ldo, const float* W, float* dX,
-                     int lddx, int acc, float* dW, float* db, hipStream_t st) {
+                     int lddx, int acc, float* dW, int dw_sk, int dw_sn, float* db, hipStream_t st) {
+  if (dw_sk == 0 && dw_sn == 0) { dw_sk = NOUT; dw_sn = 1; }
   const int rpb = 128;
   dim3 grid((K + 255) / 256, (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL((linear_small_bwd_kernel<NOUT>), grid, dim3(256), rpb * NOUT * sizeof(float), st, rows, K, rpb, X,
-                     ldx, dO, ldo, W, dX, lddx, acc, dW, db);
+                     ldx, dO, ldo, W, dX, lddx, acc, dW, dw_sk, dw_sn, db);
   return unreal_launch_status();
 }
 
@@ -304,15 +317,18 @@ int unreal_linear_small_fwd(int rows, int K, int NOUT, const float* X, int ldx, 
 }
 
 int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, const float* dO, int ldo,
-                            const float* W, float* dX, int lddx, int accumulate_dx, float* dW, float* db,
-                            void* stream) {
-  if (rows <= 0 || K <= 0 || !X || !dO || !W || !dW || ldx < K || ldo < NOUT) return UNREAL_EINVAL;
+                            const float* W, float* dX, int lddx, int accumulate_dx, float* dW, int dw_stride_k,
+                            int dw_stride_n, float* db, void* stream) {
+  if (rows <= 0 || K <= 0 || !X || !dO || !dW || ldx < K || ldo < NOUT) return UNREAL_EINVAL;
+  if (dX && !W) return UNREAL_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   switch (NOUT) {
-    case 1: return launch_small_bwd<1>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db, st);
-    case 3: return launch_small_bwd<3>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db, st);
-    case 4: return launch_small_bwd<4>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db, st);
-    case 6: return launch_small_bwd<6>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db, st);
+    case 1: return launch_small_bwd<1>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
+    case 3: return launch_small_bwd<3>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
+    case 4: return launch_small_bwd<4>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
+    case 5: return launch_small_bwd<5>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
+    case 6: return launch_small_bwd<6>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
+    case 7: return launch_small_bwd<7>(rows, K, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, dw_stride_k, dw_stride_n, db, st);
     default: return UNREAL_EINVAL;
   }
 }
@@ -349,8 +365,8 @@ int unreal_rp_loss_grad(int rows, const float* logits, const int* cls, float gra
 
 int unreal_colsum(int rows, int cols, const float* X, int ld, float* out, void* stream) {
   if (rows <= 0 || cols <= 0 || !X || !out || ld < cols) return UNREAL_EINVAL;
-  const int rpb = 256;
-  dim3 grid((cols + 255) / 256, (rows + rpb - 1) / rpb);
+  const int rpb = 1024;
+  dim3 grid((cols + 63) / 64, (rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, rpb, X, ld, out);
   return unreal_launch_status();
 }

@@ -6,8 +6,10 @@
 //
 // The transposed conv is evaluated per OUTPUT PARITY as a small dense GEMM (no scatter, no atomics):
 //   out[2a+pa][2b+pb][co] = sum_{da,db in {0,1}} sum_ci in[a-da][b-db][ci] * W[pa+2da][pb+2db][co][ci]
-// i.e. 4 GEMMs of M = 100 positions, K = 4*32, N = 1+A channels (padded to the 16-wide MFMA tile).
-// Same group/LDS organisation and MFMA operand convention as encoder.hip.
+// i.e. 4 GEMMs of M = 100 positions, K = 4*32, N = 1+A channels (padded to the 16-wide MFMA tile); wave w
+// of a frame-group owns parity w, so one weight fragment read feeds all of its position tiles.
+// Same group/LDS organisation and MFMA operand convention as encoder.hip: the next frame's inputs are
+// fetched into registers behind the current frame's math, outputs leave through LDS in 16 B/lane rows.
 #include "common.h"
 
 namespace {
@@ -16,6 +18,8 @@ constexpr int HP_LD = 36, HP_ROWS = 84;   // [81][32] + zero rows; row 81 = padd
 constexpr int DEC_LD_F = 8;               // fwd: floats per output position in LDS
 constexpr int DEC_LD_B = 12;              // bwd: floats per position (bank spreading)
 constexpr int WD_ELEMS = 4 * 4 * 2 * 4 * 16 * 4;   // 8192
+constexpr int HP_V = (C2_POS * 8 + 255) / 256;     // f32x4 per thread for one [81][32] image (3)
+constexpr int DD_V = (PC_CELLS * 8 / 4 + 255) / 256;   // f32x4 per thread for one [400][<=8] image (4)
 
 struct PcFwdArgs {
   int N, A;
@@ -38,14 +42,78 @@ __device__ __forceinline__ float deconv_w(const PcFwdArgs& p, int ky, int kx, in
   return 0.f;
 }
 
+__device__ __forceinline__ void hp_load(const float* __restrict__ src, int gtid, f32x4 (&r)[HP_V]) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+  for (int c = 0; c < HP_V; ++c) {
+    int id = gtid + 256 * c;
+    r[c] = s4[id < C2_POS * 8 ? id : gtid];
+  }
+}
+
+__device__ __forceinline__ void hp_store(float* hp, int gtid, const f32x4 (&r)[HP_V]) {
+#pragma unroll
+  for (int c = 0; c < HP_V; ++c) {
+    int id = gtid + 256 * c;
+    if (id < C2_POS * 8) *reinterpret_cast<f32x4*>(hp + (id >> 3) * HP_LD + (id & 7) * 4) = r[c];
+  }
+}
+
+// deconv of NT position tiles of output parity `par`; pre-activations (+bias) of the CO real channels -> dec
+template <int NT>
+__device__ __forceinline__ void deconv_tiles(const float* hp, const float* wd, float* dec, int par, int mt0, int i, int q,
+                                             int CO, float bias) {
+  f32x4 acc[NT];
+  int a[NT], b[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m = min((mt0 + t) * 16 + i, 99);
+    a[t] = m / 10;
+    b[t] = m % 10;
+  }
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const int da = dd >> 1, db = dd & 1;
+    int row[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int y = a[t] - da, x = b[t] - db;
+      row[t] = ((y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS) * HP_LD + 4 * q;
+    }
+#pragma unroll
+    for (int cch = 0; cch < 2; ++cch) {
+      f32x4 av[NT];
+      const f32x4 bw = *reinterpret_cast<const f32x4*>(wd + ((((par * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const f32x4*>(hp + row[t] + 16 * cch);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA16(av[t][s], bw[s], acc[t]);
+    }
+  }
+  if (i < CO) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (mt0 + t) * 16 + 4 * q + r;
+        if (m < 100)
+          dec[((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * DEC_LD_F + i] = acc[t][r] + bias;
+      }
+  }
+}
+
 __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
-  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_F * 4;
+  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_F * 4 + PC_CELLS * 8 * 4;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + WD_ELEMS * 4];
   const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
   float* hp = reinterpret_cast<float*>(smem + grp * GRP_BYTES);
   float* dec = hp + HP_ROWS * HP_LD;
+  float* dout = dec + PC_CELLS * DEC_LD_F;      // staged d_dec of the frame: [400][CO] dense
   float* wd = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
   const int A = p.A, CO = 1 + p.A;
 
@@ -60,57 +128,31 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
   float loss_acc = 0.f;
 
   const int stride = gridDim.x * 2;
+  f32x4 pre[HP_V];
+  {
+    const int n0 = blockIdx.x * 2 + grp;
+    if (n0 < p.N) {
+      hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre);
+      hp_store(hp, gtid, pre);
+    }
+  }
+  int prev = -1;
   for (int base = blockIdx.x * 2; base < p.N; base += stride) {
     const int n = base + grp;
     const bool valid = n < p.N;
-    __syncthreads();
-    if (valid) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.hp + (size_t)n * F2_DIM);
-      for (int id = gtid; id < C2_POS * 8; id += 256)
-        *reinterpret_cast<f32x4*>(hp + (id >> 3) * HP_LD + (id & 7) * 4) = src[id];
+    const int nn = n + stride;
+    const bool has_next = nn < p.N;
+    __syncthreads();  // [S0] hp of frame n staged; dout of the previous frame complete
+    if (prev >= 0 && p.d_dec) {
+      f32x4* dst = reinterpret_cast<f32x4*>(p.d_dec + (size_t)prev * PC_CELLS * CO);
+      for (int id = gtid; id < PC_CELLS * CO / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dout)[id];
     }
-    __syncthreads();
+    if (has_next) hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre);
     if (valid) {
-      for (int jb = gw; jb < 28; jb += 8) {
-        const int j0 = jb, j1 = min(jb + 4, 27);
-        const bool v1 = (jb + 4) < 28;
-        const int par0 = j0 / 7, mt0 = j0 % 7, par1 = j1 / 7, mt1 = j1 % 7;
-        const int m0 = min(mt0 * 16 + i, 99), m1 = min(mt1 * 16 + i, 99);
-        const int a0 = m0 / 10, b0 = m0 % 10, a1 = m1 / 10, b1 = m1 % 10;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          const int da = dd >> 1, db = dd & 1;
-          const int y0 = a0 - da, x0 = b0 - db, y1 = a1 - da, x1 = b1 - db;
-          const int r0 = (y0 >= 0 && y0 < 9 && x0 >= 0 && x0 < 9) ? y0 * 9 + x0 : C2_POS;
-          const int r1 = (y1 >= 0 && y1 < 9 && x1 >= 0 && x1 < 9) ? y1 * 9 + x1 : C2_POS;
-#pragma unroll
-          for (int cch = 0; cch < 2; ++cch) {
-            const f32x4 av0 = *reinterpret_cast<const f32x4*>(hp + r0 * HP_LD + 16 * cch + 4 * q);
-            const f32x4 av1 = *reinterpret_cast<const f32x4*>(hp + r1 * HP_LD + 16 * cch + 4 * q);
-            const f32x4 bw0 = *reinterpret_cast<const f32x4*>(wd + ((((par0 * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
-            const f32x4 bw1 = *reinterpret_cast<const f32x4*>(wd + ((((par1 * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              acc0 = MFMA16(av0[s], bw0[s], acc0);
-              acc1 = MFMA16(av1[s], bw1[s], acc1);
-            }
-          }
-        }
-        if (i < CO) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int m = mt0 * 16 + 4 * q + r;
-            if (m < 100)
-              dec[((2 * (m / 10) + (par0 >> 1)) * 20 + 2 * (m % 10) + (par0 & 1)) * DEC_LD_F + i] = acc0[r] + bias;
-            m = mt1 * 16 + 4 * q + r;
-            if (v1 && m < 100)
-              dec[((2 * (m / 10) + (par1 >> 1)) * 20 + 2 * (m % 10) + (par1 & 1)) * DEC_LD_F + i] = acc1[r] + bias;
-          }
-        }
-      }
+      deconv_tiles<4>(hp, wd, dec, gw, 0, i, q, CO, bias);
+      deconv_tiles<3>(hp, wd, dec, gw, 4, i, q, CO, bias);
     }
-    __syncthreads();
+    __syncthreads();  // [S1] dec complete; hp free; dout drained
     if (valid) {
       // dueling combine per output position (pre-activations in dec)
       const int act = p.action ? p.action[n] : 0;
@@ -132,13 +174,20 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
           const float diff = p.target[(size_t)n * PC_CELLS + pos] - qa;
           const float dq = on ? -p.lambda * diff * p.grad_scale : 0.f;
           if (on) loss_acc += 0.5f * p.lambda * diff * diff;
-          float* o = p.d_dec + ((size_t)n * PC_CELLS + pos) * CO;
+          float* o = dout + pos * CO;
           o[0] = vpre > 0.f ? dq : 0.f;
           for (int k = 0; k < A; ++k)
             o[1 + k] = d[1 + k] > 0.f ? dq * (((k == act) ? 1.f : 0.f) - 1.f / (float)A) : 0.f;
         }
       }
     }
+    if (has_next) hp_store(hp, gtid, pre);
+    prev = valid ? n : -1;
+  }
+  __syncthreads();
+  if (prev >= 0 && p.d_dec) {
+    f32x4* dst = reinterpret_cast<f32x4*>(p.d_dec + (size_t)prev * PC_CELLS * CO);
+    for (int id = gtid; id < PC_CELLS * CO / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dout)[id];
   }
   if (p.loss) {
     loss_acc = wave_sum(loss_acc);
@@ -156,7 +205,7 @@ struct PcBwdArgs {
 };
 
 __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
-  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_B * 4;
+  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_B * 4 + F2_DIM * 4;
   constexpr int WB_ELEMS = 4 * 2 * 4 * 32 * 4;   // [ky][c][q][ci(32)][s]; kx = q, co = 4c + s
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + WB_ELEMS * 4];
   const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
@@ -164,6 +213,7 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
   const int i = lane & 15, q = lane >> 4;
   float* hp = reinterpret_cast<float*>(smem + grp * GRP_BYTES);
   float* dec = hp + HP_ROWS * HP_LD;
+  float* dhs = dec + PC_CELLS * DEC_LD_B;        // staged d_hp of the frame: [81][32] dense
   float* wb = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
   const int A = p.A, CO = 1 + p.A;
 
@@ -189,26 +239,39 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
   for (int k = 0; k < 8; ++k) adb[k] = 0.f;
   const int nt = gw & 1;
   const int akx = i >> 3, aco = i & 7;
+  const int n_dd4 = PC_CELLS * CO / 4;           // f32x4 in one frame's d_dec
 
   const int stride = gridDim.x * 2;
+  f32x4 pre_hp[HP_V], pre_dd[DD_V];
+  __syncthreads();   // dec zero-fill visible before the first scatter
+  {
+    const int n0 = blockIdx.x * 2 + grp;
+    if (n0 < p.N) {
+      hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
+      hp_store(hp, gtid, pre_hp);
+      const float* dsrc = p.d_dec + (size_t)n0 * PC_CELLS * CO;
+      for (int e = gtid; e < PC_CELLS * CO; e += 256) dec[(e / CO) * DEC_LD_B + (e % CO)] = dsrc[e];
+    }
+  }
   for (int base = blockIdx.x * 2; base < p.N; base += stride) {
     const int n = base + grp;
     const bool valid = n < p.N;
-    __syncthreads();
-    if (valid) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.hp + (size_t)n * F2_DIM);
-      for (int id = gtid; id < C2_POS * 8; id += 256)
-        *reinterpret_cast<f32x4*>(hp + (id >> 3) * HP_LD + (id & 7) * 4) = src[id];
-      const float* dsrc = p.d_dec + (size_t)n * PC_CELLS * CO;
-      for (int pos = gtid; pos < PC_CELLS; pos += 256)
-        for (int k = 0; k < CO; ++k) {
-          float v = dsrc[pos * CO + k];
-          dec[pos * DEC_LD_B + k] = v;
-          adb[k] += v;
-        }
+    const int nn = n + stride;
+    const bool has_next = nn < p.N;
+    __syncthreads();  // [S0] hp / dec of frame n staged; dhs drained
+    if (has_next) {
+      hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre_hp);
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(p.d_dec + (size_t)nn * PC_CELLS * CO);
+#pragma unroll
+      for (int c = 0; c < DD_V; ++c) {
+        int id = gtid + 256 * c;
+        pre_dd[c] = s4[id < n_dd4 ? id : 0];
+      }
     }
-    __syncthreads();
     if (valid) {
+      for (int pos = gtid; pos < PC_CELLS; pos += 256)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) adb[k] += dec[pos * DEC_LD_B + k];      // padding columns are zero
       // (a) dgrad: d_hp[pos][ci] = sum_{ky,kx,co} d_dec[2y+ky][2x+kx][co] W[ky][kx][co][ci]
       {
         f32x4 acc[3];
@@ -233,7 +296,6 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
 #pragma unroll
               for (int jj = 0; jj < 3; ++jj) acc[jj] = MFMA16(av[jj][s], bw[s], acc[jj]);
           }
-        float* out = p.d_hp + (size_t)n * F2_DIM;
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
@@ -241,11 +303,12 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
             int pos = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
             if (pos < C2_POS) {
               int ci = nt * 16 + i;
-              out[pos * 32 + ci] = hp[pos * HP_LD + ci] > 0.f ? acc[jj][r] : 0.f;
+              dhs[pos * 32 + ci] = hp[pos * HP_LD + ci] > 0.f ? acc[jj][r] : 0.f;
             }
           }
       }
       // (b) wgrad: dW[(ky,kx,co)][ci] += sum_pos d_dec[2y+ky][2x+kx][co] * hp[pos][ci]
+#pragma unroll 3
       for (int st = 0; st < 21; ++st) {
         const int kp = min(4 * st + q, C2_POS - 1);
         const int kpb = 4 * st + q;                      // rows 81..83 of hp are zero
@@ -256,6 +319,25 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
           const float av = dec[ab + 2 * kxh * DEC_LD_B];
           aw[kxh][0] = MFMA16(av, b0, aw[kxh][0]);
           aw[kxh][1] = MFMA16(av, b1, aw[kxh][1]);
+        }
+      }
+    }
+    __syncthreads();  // [S1] all reads of hp / dec done; dhs of frame n complete
+    if (valid) {      // d_hp leaves in full 128 B lines
+      f32x4* dst = reinterpret_cast<f32x4*>(p.d_hp + (size_t)n * F2_DIM);
+      for (int id = gtid; id < F2_DIM / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dhs)[id];
+    }
+    if (has_next) {
+      hp_store(hp, gtid, pre_hp);
+#pragma unroll
+      for (int c = 0; c < DD_V; ++c) {
+        int id = gtid + 256 * c;
+        if (id < n_dd4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int el = 4 * id + e;
+            dec[(el / CO) * DEC_LD_B + (el % CO)] = pre_dd[c][e];
+          }
         }
       }
     }
@@ -273,9 +355,10 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
         if (co == 0) atomicAdd(p.dWv + (gw * 4 + kx) * 32 + ci, v);
         else if (co <= A) atomicAdd(p.dWa + ((gw * 4 + kx) * A + (co - 1)) * 32 + ci, v);
       }
-  for (int k = 0; k < CO; ++k) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
     float v = wave_sum(adb[k]);
-    if (lane == 0) {
+    if (lane == 0 && k < CO) {
       if (k == 0) atomicAdd(p.dbv, v);
       else atomicAdd(p.dba + (k - 1), v);
     }
@@ -292,6 +375,7 @@ int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const f
   if (N <= 0 || A <= 0 || A > 7 || !hp || !Wv || !bv || !Wa || !ba) return UNREAL_EINVAL;
   if (!qmax && !d_dec) return UNREAL_EINVAL;
   if (d_dec && (!action || !target || !mask || !loss)) return UNREAL_EINVAL;
+  if ((((uintptr_t)hp) | ((uintptr_t)d_dec)) & 15) return UNREAL_EINVAL;
   PcFwdArgs p{N, A, hp, Wv, bv, Wa, ba, qmax, action, target, mask, lambda, grad_scale, d_dec, d_dec ? loss : nullptr};
   int blocks = min((N + 1) / 2, 256);
   hipLaunchKernelGGL(pc_deconv_fwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, p);
@@ -302,6 +386,7 @@ int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, cons
                          float* d_hp, float* dWv, float* dbv, float* dWa, float* dba, void* stream) {
   if (N <= 0 || A <= 0 || A > 7 || !hp || !d_dec || !Wv || !Wa || !d_hp || !dWv || !dbv || !dWa || !dba)
     return UNREAL_EINVAL;
+  if ((((uintptr_t)hp) | ((uintptr_t)d_dec) | ((uintptr_t)d_hp)) & 15) return UNREAL_EINVAL;
   PcBwdArgs p{N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba};
   int blocks = min((N + 1) / 2, 256);
   hipLaunchKernelGGL(pc_deconv_bwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, p);

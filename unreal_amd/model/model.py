@@ -254,8 +254,12 @@ class UnrealModel(object):
                 if t > 0:
                     ops.gemm(0, 1, B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, Wh, 1024, gws.dh_rec, 256)
             dW = g["lstm_kernel"]
-            ops.gemm(1, 0, K_x, 1024, rows, ws.xcat, XLD, gws.d_gates, 1024, dW, 1024,
-                     flags=ops.GEMM_ATOMIC, splitk=_splitk(K_x, 1024, rows))
+            # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
+            # last_action_reward rows by the small-N outer-product kernel (no padded third tile)
+            ops.gemm(1, 0, 256, 1024, rows, ws.xcat, XLD, gws.d_gates, 1024, dW, 1024,
+                     flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, rows))
+            ops.linear_small_bwd(rows, 1024, A + 1, gws.d_gates, 1024, ws.xcat[256:], XLD, None, None, 0, False,
+                                 dW[256 * 1024:], None, dw_stride_k=1, dw_stride_n=1024)
             if T > 1:
                 r1 = (T - 1) * B
                 ops.gemm(1, 0, 256, 1024, r1, ws.h, 256, gws.d_gates[B * 1024:], 1024, dW[K_x * 1024:], 1024,

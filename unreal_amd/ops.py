@@ -260,12 +260,15 @@ def linear_small_fwd(rows, K, NOUT, X, ldx, W, b, out, ldo):
     _call("unreal_linear_small_fwd", rows, K, NOUT, ptr(X), ldx, ptr(W), ptr(b), ptr(out), ldo)
 
 
-def linear_small_bwd(rows, K, NOUT, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db):
-    _chk(X, "f32", (rows - 1) * ldx + K); _chk(dO, "f32", (rows - 1) * ldo + NOUT); _chk(W, "f32", K * NOUT)
-    _chk(dX, "f32", (rows - 1) * lddx + K, optional=True); _chk(dW, "f32", K * NOUT)
+def linear_small_bwd(rows, K, NOUT, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx, dW, db, dw_stride_k=0, dw_stride_n=0):
+    _chk(X, "f32", (rows - 1) * ldx + K); _chk(dO, "f32", (rows - 1) * ldo + NOUT)
+    _chk(W, "f32", K * NOUT, optional=dX is None)
+    _chk(dX, "f32", (rows - 1) * lddx + K, optional=True)
+    sk, sn = (dw_stride_k, dw_stride_n) if (dw_stride_k or dw_stride_n) else (NOUT, 1)
+    _chk(dW, "f32", (K - 1) * sk + (NOUT - 1) * sn + 1)
     _chk(db, "f32", NOUT, optional=True)
     _call("unreal_linear_small_bwd", rows, K, NOUT, ptr(X), ldx, ptr(dO), ldo, ptr(W), ptr(dX), lddx,
-          int(accumulate_dx), ptr(dW), ptr(db))
+          int(accumulate_dx), ptr(dW), int(dw_stride_k), int(dw_stride_n), ptr(db))
 
 
 def softmax_sample(rows, A, logits_pi, ld, u=None, action=None):
