@@ -13,7 +13,10 @@
 //       identically for A and B: lane half kq at step s supplies k = 8g + 4kq + s);
 //   KM ("k major"):            S[k][col], row stride BMN+4 floats -> conflict-free ds_read_b32.
 // 16 B/lane global loads are register-prefetched one K-tile ahead; one barrier per K-tile.
-#include "common.h"
+#include "../../unreal_amd/csrc/common.h"
+#ifndef EXP
+#define EXP 0
+#endif
 
 namespace {
 
@@ -52,7 +55,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     } else {
       k = id / (ROWS / 4);
       r = (id % (ROWS / 4)) * 4;
+#if EXP == 3
+      off = (size_t)(r0 + id / (BK / 4)) * ld + (k0 + (id % (BK / 4)) * 4);
+#else
       off = (size_t)(k0 + k) * ld + (r0 + r);
+#endif
       any = (k0 + k) < K && (r0 + r) < rows_total;
       full = (k0 + k) < K && (r0 + r + 3) < rows_total;
     }
@@ -79,8 +86,13 @@ __device__ __forceinline__ void store_tile(float* S, const f32x4 (&reg)[ROWS * B
       int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
       *reinterpret_cast<f32x4*>(S + r * (BK + 4) + k) = reg[p];
     } else {
+#if EXP == 4
+      int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
+      *reinterpret_cast<f32x4*>(S + r * (BK + 4) + k) = reg[p];
+#else
       int k = id / (ROWS / 4), r = (id % (ROWS / 4)) * 4;
       *reinterpret_cast<f32x4*>(S + k * (ROWS + 4) + r) = reg[p];
+#endif
     }
   }
 }
@@ -91,10 +103,14 @@ __device__ __forceinline__ f32x4 read_frag(const float* S, int row, int g, int k
   if (!KM) {
     return *reinterpret_cast<const f32x4*>(S + row * (BK + 4) + 8 * g + 4 * kq);
   } else {
+#if EXP == 2
+    return *reinterpret_cast<const f32x4*>(S + row * (BK + 4) + 8 * g + 4 * kq);
+#else
     f32x4 v;
 #pragma unroll
     for (int s = 0; s < 4; ++s) v[s] = S[(8 * g + 4 * kq + s) * (ROWS + 4) + row];
     return v;
+#endif
   }
 }
 
@@ -126,24 +142,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
-  // Every workgroup walks its K range from a different starting tile (and wraps): workgroups that share an
-  // operand panel would otherwise sweep the SAME lines of it in lock-step and pile onto a few L2 channels.
-  const int nkt = kt1 - kt0;
-  const int shift = (int)((blockIdx.y * 7u + blockIdx.x * 3u) % (unsigned)nkt);
-#define KT_AT(i) (kt0 + (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift))
-  load_tile<BM, A_KM>(p.A, p.lda, p.M, p.K, m0, KT_AT(0) * BK, p.vecA, ra);
-  load_tile<BN, B_KM>(p.B, p.ldb, p.N, p.K, n0, KT_AT(0) * BK, p.vecB, rb);
+  load_tile<BM, A_KM>(p.A, p.lda, p.M, p.K, m0, kt0 * BK, p.vecA, ra);
+  load_tile<BN, B_KM>(p.B, p.ldb, p.N, p.K, n0, kt0 * BK, p.vecB, rb);
   store_tile<BM, A_KM>(As0, ra);
   store_tile<BN, B_KM>(Bs0, rb);
   __syncthreads();
 
-  for (int it = 0; it < nkt; ++it) {
-    const int cur = it & 1;
-    const bool more = (it + 1) < nkt;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    const bool more = (kt + 1) < kt1;
     if (more) {
-      const int ktn = KT_AT(it + 1);
-      load_tile<BM, A_KM>(p.A, p.lda, p.M, p.K, m0, ktn * BK, p.vecA, ra);
-      load_tile<BN, B_KM>(p.B, p.ldb, p.N, p.K, n0, ktn * BK, p.vecB, rb);
+      load_tile<BM, A_KM>(p.A, p.lda, p.M, p.K, m0, (kt + 1) * BK, p.vecA, ra);
+      load_tile<BN, B_KM>(p.B, p.ldb, p.N, p.K, n0, (kt + 1) * BK, p.vecB, rb);
     }
     const float* Ac = As0 + cur * A_ELEMS;
     const float* Bc = Bs0 + cur * B_ELEMS;
@@ -247,7 +257,7 @@ int launch(int ta, int tb, const GemmArgs& a, int splitk, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
+extern "C" int exp_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                                int ldb, float* C, int ldc, const float* bias, const float* mask, int ldm, int flags,
                                int splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return UNREAL_EINVAL;
