@@ -149,6 +149,16 @@ def main():
     mac = ENC_BWD_MAC if "bwd" in args.timed_kernel else ENC_FWD_MAC
     avg_ms = kt["ms"] / max(kt["launches"], 1)
     achieved = (2.0 * mac * frames_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the per-frame figure comes
+    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_encoder.json, corrected
+    # as MI355X_MICROARCH.md prescribes) scaled by the frames one launch processed.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_encoder.json")))
+        key = "encoder_bwd" if "bwd" in args.timed_kernel else "encoder_fwd_save_c1"
+        traffic = pmc[key]["hbm_bytes_per_frame"] * frames_per_launch
+    except Exception:
+        pass
     out = {
         "metric": "env-steps/sec (whole node), UNREAL maze 84x84",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +172,9 @@ def main():
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
         "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "launches": kt["launches"], "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass)",
+                     "algorithmic_bytes_per_launch": 57136.0 * frames_per_launch,
+                     "launches": kt["launches"], "avg_launch_ms": avg_ms,
                      "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),
                      "whole_path_frac_fp32_mfma": value * 69.67e6 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world),
                      "whole_path_frac_hbm_u8": value * 114396.0 / (HBM_PEAK_GBS * 1e9 * world)},
