@@ -109,8 +109,9 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("UNREAL_FORCE_DEVICE", local_rank))   # rehearsal: several ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     flags, net, tr = build_trainer(args, rank, world, device)
     T = flags.n_step_TD
