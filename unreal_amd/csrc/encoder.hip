@@ -36,19 +36,6 @@ __device__ __forceinline__ void cvt4(uint32_t w, float (&f)[4]) {
   f[3] = (float)(w >> 24);
 }
 
-// conv1 weights into registers: reg (p,c,s) holds W1[k][j], k = (2p + cc/6)*24 + 4*(cc%6) + s, cc = 3q + c
-__device__ __forceinline__ void load_w1_regs(const float* __restrict__ W1, int q, int j, float (&w)[4][3][4]) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      int cc = 3 * q + c;
-      int kb = (2 * p + cc / 6) * 24 + 4 * (cc % 6);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) w[p][c][s] = W1[(kb + s) * 16 + j];
-    }
-}
-
 __device__ __forceinline__ void frame_load(const uint8_t* __restrict__ src, int gtid, u32x4 (&r)[FR_V]) {
   const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
 #pragma unroll
@@ -67,29 +54,84 @@ __device__ __forceinline__ void frame_store(uint8_t* dst, int gtid, const u32x4 
   }
 }
 
+// ---- conv1 forward as EXACT-PRODUCT bf16 MFMAs -----------------------------------------------------
+// The uint8 pixel is exact in bf16 (8 significant bits) and every fp32 weight is split once per kernel into
+// three bf16 terms w = wh + wm + wl (8 + 8 + 8 = 24 mantissa bits, residuals computed exactly in fp32), so
+// three v_mfma_f32_16x16x32_bf16 per 32-deep K chunk give products that are exact in fp32 and are
+// accumulated in fp32 -- fp32-grade numerics at 16/3 of the fp32 MFMA rate.  Lane (i = l&15, q = l>>4)
+// supplies A[pos i][k = 32kc + 8q + j] and B[k = 32kc + 8q + j][cout i], j = 0..7; 8 consecutive k never
+// straddle a patch row (24 bytes per ky), so A is two aligned 32-bit LDS reads of the uint8 frame.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef u32x4 u32x4v;
+
+__device__ __forceinline__ uint32_t bf16_rne_bits(float x) {     // fp32 -> bf16 (round to nearest even), as bits
+  uint32_t u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__device__ __forceinline__ void split3(float w, uint32_t (&t)[3]) {
+  t[0] = bf16_rne_bits(w);
+  float r = w - __uint_as_float(t[0] << 16);
+  t[1] = bf16_rne_bits(r);
+  r = r - __uint_as_float(t[1] << 16);
+  t[2] = bf16_rne_bits(r);                  // exact: at most 8 significant bits are left
+}
+
+// wb[kc][term]: 8 bf16 (k = 32kc + 8q + j) of output channel j_out, packed two per dword
+__device__ __forceinline__ void load_w1_bf16x3(const float* __restrict__ W1, int q, int j_out, u32x4v (&wb)[6][3]) {
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) {
+    uint32_t pk[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t lo[3], hi[3];
+      split3(W1[(32 * kc + 8 * q + 2 * e) * 16 + j_out], lo);
+      split3(W1[(32 * kc + 8 * q + 2 * e + 1) * 16 + j_out], hi);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) pk[t][e] = lo[t] | (hi[t] << 16);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wb[kc][t] = (u32x4v){pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
+  }
+}
+
+// 8 uint8 (two dwords) -> 8 bf16: float(byte) has <= 8 significant bits, so its upper 16 bits ARE the bf16
+__device__ __forceinline__ bf16x8 u8x8_to_bf16(uint32_t w0, uint32_t w1) {
+  float f[8];
+  f[0] = (float)(w0 & 0xffu); f[1] = (float)((w0 >> 8) & 0xffu); f[2] = (float)((w0 >> 16) & 0xffu); f[3] = (float)(w0 >> 24);
+  f[4] = (float)(w1 & 0xffu); f[5] = (float)((w1 >> 8) & 0xffu); f[6] = (float)((w1 >> 16) & 0xffu); f[7] = (float)(w1 >> 24);
+  u32x4v r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    r[e] = __builtin_amdgcn_perm(__float_as_uint(f[2 * e + 1]), __float_as_uint(f[2 * e]), 0x07060302u);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // conv1 for TWO (or one) 16-position tiles: fr (uint8 LDS) -> c1 (fp32 LDS, post-ReLU)
 template <bool TWO>
-__device__ __forceinline__ void conv1_tile_pair(const uint8_t* fr, float* c1, const float (&w1)[4][3][4], float bias_j,
-                                                float scale, int ta, int tb, int i, int q) {
+__device__ __forceinline__ void conv1_tile_pair(const uint8_t* fr, float* c1, const u32x4v (&wb)[6][3],
+                                                const int (&koff)[6], float bias_j, float scale, int ta, int tb, int i,
+                                                int q) {
   const int pa = ta * 16 + i, pb = tb * 16 + i;
-  const int ba = (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
-  const int bb = (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
+  const uint8_t* fa = fr + (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
+  const uint8_t* fb = fr + (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
   f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int cc = 3 * q + c;
-      const int off = (2 * p + cc / 6) * FRAME_ROW_BYTES + 4 * (cc % 6);
-      float fa[4], fb[4];
-      cvt4(*reinterpret_cast<const uint32_t*>(fr + ba + off), fa);
-      if (TWO) cvt4(*reinterpret_cast<const uint32_t*>(fr + bb + off), fb);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acca = MFMA16(fa[s], w1[p][c][s], acca);
-        if (TWO) accb = MFMA16(fb[s], w1[p][c][s], accb);
-      }
+  for (int kc = 0; kc < 6; ++kc) {
+    const uint32_t* pa32 = reinterpret_cast<const uint32_t*>(fa + koff[kc]);
+    const bf16x8 aa = u8x8_to_bf16(pa32[0], pa32[1]);
+    bf16x8 ab;
+    if (TWO) {
+      const uint32_t* pb32 = reinterpret_cast<const uint32_t*>(fb + koff[kc]);
+      ab = u8x8_to_bf16(pb32[0], pb32[1]);
     }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bf16x8 bw = __builtin_bit_cast(bf16x8, wb[kc][t]);
+      acca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa, bw, acca, 0, 0, 0);
+      if (TWO) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bw, accb, 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     c1[(ta * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * acca[r] + bias_j, 0.f);
@@ -118,8 +160,11 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
     int k = (kc >> 2) * 64 + qq * 16 + 4 * (kc & 3) + s;
     w2s[e] = W2[k * 32 + n];
   }
-  float w1[4][3][4];
-  load_w1_regs(W1, q, i, w1);
+  u32x4v w1[6][3];
+  load_w1_bf16x3(W1, q, i, w1);
+  int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
   const float bias1 = b1[i];
   const int nt = gw & 1;                       // this wave's conv2 N-tile
   const float bias2 = b2[nt * 16 + i];
@@ -146,8 +191,8 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
     }
     if (valid) {
       for (int tt = gw; tt < 25; tt += 8) {
-        if (tt + 4 < 25) conv1_tile_pair<true>(fr, c1, w1, bias1, scale, tt, tt + 4, i, q);
-        else conv1_tile_pair<false>(fr, c1, w1, bias1, scale, tt, tt, i, q);
+        if (tt + 4 < 25) conv1_tile_pair<true>(fr, c1, w1, koff, bias1, scale, tt, tt + 4, i, q);
+        else conv1_tile_pair<false>(fr, c1, w1, koff, bias1, scale, tt, tt, i, q);
       }
     }
     __syncthreads();  // c1 complete; fr free; f2s drained
