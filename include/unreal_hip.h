@@ -39,6 +39,16 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
                      int* score_valid, int reset_on_terminal, int track_score, void* stream);
 int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
                       const int* count, uint8_t* frames, void* stream);
+/* host-fed environments (environment/lab_environment.py:78-119 contract): `staged` holds one uint8
+ * frame per actor (post-reset observation where terminals[b] != 0) */
+int unreal_hostfed_step(int B, int H1, const uint8_t* staged, const int* actions, const float* rewards,
+                        const int* terminals, const int* active, int* last_action, float* last_reward, int* count,
+                        uint8_t* frames, float* r_reward, int* r_action, int* r_terminal, int* r_last_action,
+                        float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
+                        float* episode_reward, float* score_out, int* score_valid, int reset_on_terminal,
+                        int track_score, int clip_reward, float pc_denom, void* stream);
+int unreal_hostfed_reset(int B, int H1, const int* mask, const uint8_t* staged, int* last_action, float* last_reward,
+                         const int* count, uint8_t* frames, void* stream);
 /* generic _calc_pixel_change on stored uint8 frames: out[n][400] = sum_{4x4x3}|new-old| / denom */
 int unreal_pixel_change_u8(int N, const uint8_t* frames, const int* idx_new, const int* idx_old,
                            float denom, float* out, void* stream);
@@ -50,8 +60,11 @@ int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int high, in
 /* ---- replay sampling (train/experience.py:100-118, 121-153; train/trainer.py:427-434) ------------ */
 int unreal_replay_sample_seq(int B, int H, int H1, int L, const int* start_draw, const int* count,
                              const int* r_terminal, int* seq_idx /*[L][B]*/, int* seq_len /*[B]*/, void* stream);
+/* mode 0: this fork's buckets (reward > 0 | rest); mode 1: upstream / Lab replay (reward != 0 | reward == 0,
+ * train/experience_lab_ver.py:76-80, 124-141) */
 int unreal_replay_sample_rp(int B, int H, int H1, const int* coin, const double* u, const int* count,
-                            const float* r_reward, int* rp_idx /*[B][3]*/, int* rp_class /*[B]*/, void* stream);
+                            const float* r_reward, int* rp_idx /*[B][3]*/, int* rp_class /*[B]*/, int mode,
+                            void* stream);
 
 /* ---- return scans (train/trainer.py:298-324, 354-372, 394-406), fp64 like the reference ----------- */
 int unreal_base_returns(int B, int T, const float* rewards, const float* values, const int* n_steps,
@@ -63,8 +76,9 @@ int unreal_pc_returns(int B, int L, const int* seq_idx, const int* seq_len, cons
                       const int* r_terminal, const float* boot_qmax, double gamma_pc, float* R_out, void* stream);
 
 /* ---- rollout bookkeeping (train/experience.py:35-46; train/trainer.py:236-296; model.py:625-628) -- */
+/* clip_reward != 0: the reward column is np.clip(r, -1, 1) (ExperienceFrame of train/experience_lab_ver.py:14,18) */
 int unreal_lar_fill(int rows, int A, const int* last_action, const float* last_reward, const int* idx, float* xcat,
-                    int ld, int col0, void* stream);
+                    int ld, int col0, int clip_reward, void* stream);
 int unreal_gather_i32(int rows, const int* src, const int* idx, int* out, void* stream);
 int unreal_rollout_advance(int B, const int* terminal_t, int* active, int* active_log_t, int* n_steps,
                            int* terminal_end, void* stream);

@@ -36,8 +36,18 @@ class Frame(object):
         return concat_action_and_reward(self.action, action_size, self.reward)
 
 
+def clip_frame(frame):
+    """experience_lab_ver.py:14,18: reward and last_reward are clipped when the frame is created."""
+    frame.reward = float(np.clip(frame.reward, -1, 1))
+    frame.last_reward = float(np.clip(frame.last_reward, -1, 1))
+    return frame
+
+
 class OracleExperience(object):
-    def __init__(self, history_size, random_state=None):
+    def __init__(self, history_size, random_state=None, lab_ver=False):
+        # lab_ver: upstream replay of /root/reference/train/experience_lab_ver.py (zero / non-zero reward buckets
+        # :53-55,76-80,124-141; rewards are clipped to [-1, 1] when the frame is created :14,18 -- see clip_frame)
+        self.lab_ver = lab_ver
         self.H = history_size
         self.frames = {}            # absolute index -> Frame (only the live window is kept)
         self.count = 0              # frames ever appended (absolute index of the next frame)
@@ -62,6 +72,8 @@ class OracleExperience(object):
         else (zero AND negative rewards) goes to 'neg' in this fork (:77-80).
         """
         lo = self.top + 3
+        if self.lab_ver:     # 'positive' selects the non-zero bucket, the other one is the zero bucket
+            return [i for i in range(lo, self.count) if (self.frames[i].reward != 0) == positive]
         return [i for i in range(lo, self.count) if (self.frames[i].reward > 0) == positive]
 
     # -- mutation ------------------------------------------------------------------------------

@@ -20,7 +20,7 @@ import torch
 
 from . import model as M
 from .maze import OracleMaze
-from .experience import OracleExperience, Frame, concat_action_and_reward
+from .experience import OracleExperience, Frame, concat_action_and_reward, clip_frame
 from .rmsprop import OracleRMSProp
 
 
@@ -73,13 +73,14 @@ class ExplicitDraws(object):
 
 
 class OracleActor(object):
-    def __init__(self, cfg, draws, dtype=torch.float32):
+    def __init__(self, cfg, draws, dtype=torch.float32, env=None):
         self.cfg = cfg
         self.A = cfg["action_size"]
         self.draws = draws
         self.dtype = dtype
-        self.env = OracleMaze()
-        self.exp = OracleExperience(cfg["experience_history_size"])
+        self.env = env if env is not None else OracleMaze()
+        self.lab_ver = bool(cfg.get("lab_ver", False))      # upstream replay (experience_lab_ver.py)
+        self.exp = OracleExperience(cfg["experience_history_size"], lab_ver=self.lab_ver)
         self.local_t = 0
         self.episode_reward = 0
         self.reset_state()
@@ -110,11 +111,15 @@ class OracleActor(object):
         pi, _ = self.run_base_policy_and_value(p, prev_state, lar)
         action = self.draws.choose_action(pi)
         _, reward, terminal, pc = env.process(action)
-        self.exp.add_frame(Frame(prev_state, reward, action, terminal, pc, last_action, last_reward))
+        self.exp.add_frame(self._frame(prev_state, reward, action, terminal, pc, last_action, last_reward))
         if terminal:
             env.reset()
         if self.exp.is_full():
             env.reset()
+
+    def _frame(self, *a):
+        f = Frame(*a)
+        return clip_frame(f) if self.lab_ver else f
 
     def process_base(self, p):                       # trainer.py:218-336
         cfg, env = self.cfg, self.env
@@ -133,7 +138,7 @@ class OracleActor(object):
             values.append(v)
             prev_state = env.last_state
             new_state, reward, terminal, pc = env.process(action)
-            frame = Frame(prev_state, reward, action, terminal, pc, last_action, last_reward)
+            frame = self._frame(prev_state, reward, action, terminal, pc, last_action, last_reward)
             self.exp.add_frame(frame)
             self.episode_reward += reward
             rewards.append(reward)
@@ -255,7 +260,7 @@ LOSS_KEYS = ("total_loss", "base_loss", "policy_loss", "value_loss", "pc_loss", 
 
 
 class OracleTrainer(object):
-    def __init__(self, cfg, n_actors=1, draws=None, seed=0, dtype=torch.float32, params=None):
+    def __init__(self, cfg, n_actors=1, draws=None, seed=0, dtype=torch.float32, params=None, envs=None):
         self.cfg = dict(cfg)
         self.dtype = dtype
         kw = dict(use_lstm=cfg["use_lstm"], use_pixel_change=cfg.get("use_pixel_change", False),
@@ -266,7 +271,7 @@ class OracleTrainer(object):
         if draws is None:
             shared = RefDraws(np.random.RandomState(0xA3C))
             draws = [shared] * n_actors
-        self.actors = [OracleActor(self.cfg, draws[i], dtype) for i in range(n_actors)]
+        self.actors = [OracleActor(self.cfg, draws[i], dtype, env=(envs[i] if envs else None)) for i in range(n_actors)]
         npdt = np.float32 if dtype == torch.float32 else np.float64
         self.opt = OracleRMSProp(decay=cfg["rmsp_alpha"], momentum=0.0, epsilon=cfg["rmsp_epsilon"],
                                  clip_norm=cfg["grad_norm_clip"], dtype=npdt)

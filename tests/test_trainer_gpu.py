@@ -41,21 +41,25 @@ def _cfg(use_lstm, aux, H, T):
                 initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
 
 
-def _build(cfg, B, seed):
+def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=1.0):
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
     from unreal_amd.train.rmsprop_applier import RMSPropApplier
     from unreal_amd.train.trainer import Trainer, PhiloxDraws
     Environment.action_size = -1
-    net = UnrealModel(4, 0, -1, cfg["use_lstm"], cfg["use_pixel_change"], cfg["use_value_replay"],
-                      cfg["use_reward_prediction"], cfg["pixel_change_lambda"], cfg["entropy_beta"], DEV, seed=seed)
+    A = Environment.get_action_size(env_type, "")
+    assert A == cfg["action_size"]
+    net = UnrealModel(A, 0, -1, cfg["use_lstm"], cfg["use_pixel_change"], cfg["use_value_replay"],
+                      cfg["use_reward_prediction"], cfg["pixel_change_lambda"], cfg["entropy_beta"], DEV, seed=seed,
+                      frame_scale=frame_scale)
     applier = RMSPropApplier(None, decay=cfg["rmsp_alpha"], momentum=0.0, epsilon=cfg["rmsp_epsilon"],
                              clip_norm=cfg["grad_norm_clip"], device=DEV)
     draws = RecordingDraws(PhiloxDraws(0xA3C, 0))
-    tr = Trainer(0, net, 7.0711e-4, None, applier, "maze", "", cfg["use_lstm"], cfg["use_pixel_change"],
+    tr = Trainer(0, net, 7.0711e-4, None, applier, env_type, "", cfg["use_lstm"], cfg["use_pixel_change"],
                  cfg["use_value_replay"], cfg["use_reward_prediction"], cfg["pixel_change_lambda"],
                  cfg["entropy_beta"], cfg["local_t_max"], cfg["n_step_TD"], cfg["gamma"], cfg["gamma_pc"],
-                 cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws)
+                 cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws,
+                 simulator=simulator)
     tr.prepare()
     return net, applier, tr, draws
 
@@ -232,3 +236,86 @@ def test_maze_environment_reference_surface():
         np.testing.assert_array_equal(pc, pc2.astype(np.float32))
         assert (reward, terminal) == (r2, t2)
     env.stop()
+
+
+def test_hostfed_lab_contract_matches_oracle():
+    """SURVEY 8f-1 / BASELINE config 4: host simulators (synthetic stand-in for DeepMind Lab: uint8 frames, A = 6,
+    sparse rewards incl. values > 1, fixed-length episodes) -> pinned staging -> HBM ring -> the same batched
+    learner, against the oracle running the Lab wrapper contract (lab_environment.py:78-119) with the upstream
+    replay semantics (experience_lab_ver.py) actor by actor.  Parity unpinned by the reference (no Lab fixtures)."""
+    from oracle.hostfed import OracleLabEnv
+    from unreal_amd.environment.synthetic_sim import SyntheticBatchSimulator, SyntheticActorSim
+    B, H, T = 3, 40, 20
+    cfg = _cfg(True, True, H, T)
+    cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
+    kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
+    sim = SyntheticBatchSimulator(B, seed=4, **kw)
+    net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0)
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+    edraws = [ExplicitDraws() for _ in range(B)]
+    envs = [OracleLabEnv(SyntheticActorSim(4 * 100003 + b, **kw), 6) for b in range(B)]
+    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params, envs=envs)
+    while not tr._full:
+        assert tr.process(None, 0) == (0, None)
+    assert len(draws.log) == H
+    for step_u in draws.log:
+        for b in range(B):
+            edraws[b].action_u.append(float(step_u[b]))
+    orc.fill()
+    np.testing.assert_array_equal(tr.ring.count.cpu().numpy(), [a.exp.count for a in orc.actors])
+    # ring contents after the fill: frames, clipped rewards, terminals, pixel change
+    from unreal_amd import ops
+    H1 = H + 1
+    fr = tr.ring.frames.cpu().numpy().reshape(B, H1, 84, 84, 3)
+    rr = tr.ring.r_reward.cpu().numpy().reshape(B, H1)
+    rt = tr.ring.r_terminal.cpu().numpy().reshape(B, H1)
+    rpc = tr.ring.r_pc.cpu().numpy().reshape(B, H1, 20, 20)
+    saw_clip = False
+    for b in range(B):
+        x = orc.actors[b].exp
+        for i in range(x.top, x.count):
+            f = x.frames[i]
+            np.testing.assert_array_equal(fr[b, i % H1], np.rint(f.state['image'] * 255.0).astype(np.uint8))
+            assert rr[b, i % H1] == f.reward and bool(rt[b, i % H1]) == bool(f.terminal)
+            # reference: float32 arithmetic on obs/255; kernel: exact integer SAD / (48*255) -> 1e-6 relative
+            np.testing.assert_allclose(rpc[b, i % H1], f.pixel_change, rtol=2e-6, atol=1e-7)
+        saw_clip |= any(abs(orc.actors[b].env.last_reward) > 1 for _ in [0])
+    global_t = 0
+    for it in range(3):
+        draws.log.clear()
+        lr = tr._anneal_learning_rate(global_t)
+        tr.compute_gradients()
+        g_dev = {k: v.detach().cpu().double().numpy().copy() for k, v in net.g.items()}
+        tr.last_grad_norm = applier.step(net.params.flat, net.grads.flat, lr)
+        norm_dev = float(tr.last_grad_norm.cpu()[0])
+        tr.stats.zero_()
+        ops.rollout_stats(B, tr.n_steps, tr.ring.score_valid, tr.ring.score_out, tr.stats)
+        steps_dev, episodes_dev, score_dev = tr.read_stats()
+        losses_dev = tr._publish_losses()
+        u_act = draws.log[0].reshape(T, B)
+        for b in range(B):
+            edraws[b].action_u = [float(u_act[t, b]) for t in range(T)]
+            edraws[b].seq_starts = [int(draws.log[1][b]), int(draws.log[2][b])]
+            edraws[b].rp_coin = [int(draws.log[3][b])]
+            edraws[b].rp_u = [float(draws.log[4][b])]
+        steps_o, infos, losses_o, mean_g, norm_o = orc.process_batched(global_t)
+        n_dev = tr.n_steps.cpu().numpy()
+        acts = tr.actions.cpu().numpy().reshape(T, B)
+        rews = tr.rewards.cpu().numpy().reshape(T, B)
+        assert steps_dev == steps_o
+        for b in range(B):
+            n = infos[b]["n"]
+            assert n_dev[b] == n and list(acts[:n, b]) == infos[b]["actions"]
+            assert list(rews[:n, b]) == [float(r) for r in infos[b]["rewards"]]      # raw (unclipped) rewards
+        sc = [i["score"] for i in infos if i["score"] is not None]
+        assert episodes_dev == len(sc) and (not sc or abs(score_dev - sum(sc)) < 1e-5)
+        for key in ("policy_loss", "value_loss", "pc_loss", "vr_loss", "rp_loss", "total_loss"):
+            want = np.mean([l[key] for l in losses_o])
+            assert abs(losses_dev[key] - want) <= 3e-4 + 3e-4 * abs(want), (it, key, losses_dev[key], want)
+        for (name, _), gref in zip(orc.params.items(), mean_g):
+            gr = gref.numpy().reshape(-1)
+            tol = 1e-5 + 3e-4 * np.abs(gr).max()
+            assert np.abs(g_dev[name] - gr).max() <= tol, (it, name, np.abs(g_dev[name] - gr).max(), np.abs(gr).max())
+        assert abs(norm_dev - norm_o) <= 2e-4 * max(1.0, norm_o)
+        global_t += steps_dev
+    assert any(abs(r) > 1 for a in orc.actors for r in [f.last_reward for f in a.exp.frames.values()]) is False

@@ -204,6 +204,122 @@ __global__ __launch_bounds__(256) void pixel_change_u8_kernel(int N, const uint8
   out[g] = (float)s / denom;
 }
 
+// ---- host-fed environments (the DeepMind-Lab frame/reward contract) -----------------------
+// The simulator runs on host cores; one uint8 frame per actor is staged in HBM (`staged`, after an H2D copy
+// from pinned memory) and this kernel does what MazeEnvironment's kernel does for the maze: pixel change
+// against the stored previous frame, commit of the ring slot, copy of the new observation into the next slot.
+// Contract restated from /root/reference/environment/lab_environment.py:104-119: on a terminal step the
+// state is the PREVIOUS state (pixel change 0) and the staged frame is the post-reset observation the
+// trainer's env.reset() obtains (train/trainer.py:201-202, 292).  `clip_reward` applies the upstream replay's
+// np.clip(reward, -1, 1) to the STORED reward / last_reward (train/experience_lab_ver.py:14,18); the
+// environment's own last_reward stays raw.
+struct HostFedArgs {
+  int B, H1;
+  const uint8_t* staged;
+  const int* actions;
+  const float* rewards;
+  const int* terminals;
+  const int* active;
+  int* last_action;
+  float* last_reward;
+  int* count;
+  uint8_t* frames;
+  float* r_reward;
+  int* r_action;
+  int* r_terminal;
+  int* r_last_action;
+  float* r_last_reward;
+  float* r_pc;
+  float* out_reward;
+  int* out_terminal;
+  float* episode_reward;
+  float* score_out;
+  int* score_valid;
+  int reset_on_terminal, track_score, clip_reward;
+  float pc_denom;
+};
+
+__device__ __forceinline__ float clip1(float r, int on) { return on ? fminf(fmaxf(r, -1.f), 1.f) : r; }
+
+__global__ __launch_bounds__(256) void hostfed_step_kernel(HostFedArgs p) {
+  const int b = blockIdx.x;
+  if (p.active && !p.active[b]) return;
+  const int H1 = p.H1;
+  const int a = p.actions[b];
+  const float reward = p.rewards[b];
+  const bool terminal = p.terminals[b] != 0;
+  const int cnt = p.count[b];
+  const int la = p.last_action[b];
+  const float lr = p.last_reward[b];
+  const int slot = cnt % H1;
+  const int prev_term = cnt > 0 ? p.r_terminal[(size_t)b * H1 + (cnt - 1) % H1] : 0;
+  float ep = p.track_score ? p.episode_reward[b] : 0.f;
+  __syncthreads();
+  const size_t base = (size_t)b * H1 + slot;
+  const uint8_t* fnew = p.staged + (size_t)b * FRAME_BYTES;
+  const uint8_t* fold = p.frames + base * FRAME_BYTES;
+  for (int c = threadIdx.x; c < PC_CELLS; c += blockDim.x) {
+    int s = 0;
+    if (!terminal) {
+      const int i = c / 20, j = c - i * 20;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int off = (4 * i + 2 + r) * FRAME_ROW_BYTES + (4 * j + 2) * 3;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s += abs((int)fnew[off + k] - (int)fold[off + k]);
+      }
+    }
+    p.r_pc[base * PC_CELLS + c] = (float)s / p.pc_denom;
+  }
+  const bool discard = terminal && cnt > 0 && prev_term;
+  const int ncnt = discard ? cnt : cnt + 1;
+  const bool reset = terminal && p.reset_on_terminal;
+  const int nslot = ncnt % H1;
+  __syncthreads();   // pixel change has read the old frame before a discard could overwrite the same slot
+  {
+    const uint4* s4 = reinterpret_cast<const uint4*>(fnew);
+    uint4* d4 = reinterpret_cast<uint4*>(p.frames + ((size_t)b * H1 + nslot) * FRAME_BYTES);
+    for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) d4[c] = s4[c];
+  }
+  if (threadIdx.x == 0) {
+    p.r_reward[base] = clip1(reward, p.clip_reward);
+    p.r_action[base] = a;
+    p.r_terminal[base] = terminal ? 1 : 0;
+    p.r_last_action[base] = la;
+    p.r_last_reward[base] = clip1(lr, p.clip_reward);
+    p.count[b] = ncnt;
+    p.last_action[b] = reset ? 0 : a;
+    p.last_reward[b] = reset ? 0.f : reward;
+    if (p.out_reward) p.out_reward[b] = reward;
+    if (p.out_terminal) p.out_terminal[b] = terminal ? 1 : 0;
+    if (p.track_score) {
+      ep += reward;
+      if (terminal) {
+        p.score_out[b] = ep;
+        p.score_valid[b] = 1;
+        ep = 0.f;
+      }
+      p.episode_reward[b] = ep;
+    }
+  }
+}
+
+// env.reset() for host-fed actors: the staged post-reset observation becomes the current observation
+__global__ __launch_bounds__(256) void hostfed_reset_kernel(int B, int H1, const int* mask, const uint8_t* staged,
+                                                            int* last_action, float* last_reward, const int* count,
+                                                            uint8_t* frames) {
+  const int b = blockIdx.x;
+  if (mask && !mask[b]) return;
+  const int slot = count[b] % H1;
+  const uint4* s4 = reinterpret_cast<const uint4*>(staged + (size_t)b * FRAME_BYTES);
+  uint4* d4 = reinterpret_cast<uint4*>(frames + ((size_t)b * H1 + slot) * FRAME_BYTES);
+  for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) d4[c] = s4[c];
+  if (threadIdx.x == 0) {
+    last_action[b] = 0;
+    last_reward[b] = 0.f;
+  }
+}
+
 // ---- Philox4x32-10 counter RNG: key = seed, counter = (index, stream) ------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -264,6 +380,32 @@ int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action
                       const int* count, uint8_t* frames, void* stream) {
   if (B <= 0 || H1 < 2 || !pos || !count || !frames) return UNREAL_EINVAL;
   hipLaunchKernelGGL(maze_reset_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H1, mask, pos,
+                     last_action, last_reward, count, frames);
+  return unreal_launch_status();
+}
+
+int unreal_hostfed_step(int B, int H1, const uint8_t* staged, const int* actions, const float* rewards,
+                        const int* terminals, const int* active, int* last_action, float* last_reward, int* count,
+                        uint8_t* frames, float* r_reward, int* r_action, int* r_terminal, int* r_last_action,
+                        float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
+                        float* episode_reward, float* score_out, int* score_valid, int reset_on_terminal,
+                        int track_score, int clip_reward, float pc_denom, void* stream) {
+  if (B <= 0 || H1 < 2 || !staged || !actions || !rewards || !terminals || !count || !frames || pc_denom <= 0.f)
+    return UNREAL_EINVAL;
+  if (track_score && (!episode_reward || !score_out || !score_valid)) return UNREAL_EINVAL;
+  if ((((uintptr_t)staged) | ((uintptr_t)frames)) & 15) return UNREAL_EINVAL;
+  HostFedArgs p{B, H1, staged, actions, rewards, terminals, active, last_action, last_reward, count, frames, r_reward,
+                r_action, r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
+                score_out, score_valid, reset_on_terminal, track_score, clip_reward, pc_denom};
+  hipLaunchKernelGGL(hostfed_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+  return unreal_launch_status();
+}
+
+int unreal_hostfed_reset(int B, int H1, const int* mask, const uint8_t* staged, int* last_action, float* last_reward,
+                         const int* count, uint8_t* frames, void* stream) {
+  if (B <= 0 || H1 < 2 || !staged || !count || !frames || !last_action || !last_reward) return UNREAL_EINVAL;
+  if ((((uintptr_t)staged) | ((uintptr_t)frames)) & 15) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(hostfed_reset_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H1, mask, staged,
                      last_action, last_reward, count, frames);
   return unreal_launch_status();
 }

@@ -35,9 +35,11 @@ __global__ void sample_seq_kernel(int B, int H, int H1, int L, const int* start_
 }
 
 // one wave per actor
+// bucket rule: mode 0 = this fork (reward > 0 | everything else, experience.py:76-80);
+//              mode 1 = upstream / Lab replay (reward != 0 | reward == 0, experience_lab_ver.py:76-80)
 __global__ __launch_bounds__(64) void sample_rp_kernel(int B, int H, int H1, const int* coin, const double* u,
                                                        const int* count, const float* r_reward, int* rp_idx,
-                                                       int* rp_class) {
+                                                       int* rp_class, int mode) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int cnt = count[b];
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(64) void sample_rp_kernel(int B, int H, int H1, con
   int npos = 0;
   for (int c = 0; c < nw; c += 64) {
     int a = lo + c + lane;
-    bool ispos = (a < cnt) && (r_reward[rb + a % H1] > 0.f);
+    const float rv = (a < cnt) ? r_reward[rb + a % H1] : 0.f;
+    bool ispos = (a < cnt) && (mode ? (rv != 0.f) : (rv > 0.f));
     npos += __popcll(__ballot(ispos));
   }
   const int nneg = nw - npos;
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(64) void sample_rp_kernel(int B, int H, int H1, con
   for (int c = 0; c < nw; c += 64) {
     int a = lo + c + lane;
     bool in = a < cnt;
-    bool ispos = in && (r_reward[rb + a % H1] > 0.f);
+    const float rv = in ? r_reward[rb + a % H1] : 0.f;
+    bool ispos = in && (mode ? (rv != 0.f) : (rv > 0.f));
     bool member = in && (ispos != from_neg);
     unsigned long long m = __ballot(member);
     int pc = __popcll(m);
@@ -130,7 +134,7 @@ __global__ void pc_returns_kernel(int B, int L, const int* seq_idx, const int* s
 
 // xcat[row][256 .. 256+A] = one_hot(last_action) || last_reward ; columns up to ld zeroed
 __global__ void lar_fill_kernel(int rows, int A, const int* last_action, const float* last_reward, const int* idx,
-                                float* xcat, int ld, int col0) {
+                                float* xcat, int ld, int col0, int clip) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int w = ld - col0;
   if (g >= rows * w) return;
@@ -138,7 +142,7 @@ __global__ void lar_fill_kernel(int rows, int A, const int* last_action, const f
   int src = idx ? idx[r] : r;
   float v = 0.f;
   if (k < A) v = (last_action[src] == k) ? 1.f : 0.f;
-  else if (k == A) v = last_reward[src];
+  else if (k == A) v = clip ? fminf(fmaxf(last_reward[src], -1.f), 1.f) : last_reward[src];
   xcat[(size_t)r * ld + col0 + k] = v;
 }
 
@@ -224,11 +228,11 @@ int unreal_replay_sample_seq(int B, int H, int H1, int L, const int* start_draw,
 }
 
 int unreal_replay_sample_rp(int B, int H, int H1, const int* coin, const double* u, const int* count,
-                            const float* r_reward, int* rp_idx, int* rp_class, void* stream) {
+                            const float* r_reward, int* rp_idx, int* rp_class, int mode, void* stream) {
   if (B <= 0 || H1 != H + 1 || H < 4 || !coin || !u || !count || !r_reward || !rp_idx || !rp_class)
     return UNREAL_EINVAL;
   hipLaunchKernelGGL(sample_rp_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, B, H, H1, coin, u, count,
-                     r_reward, rp_idx, rp_class);
+                     r_reward, rp_idx, rp_class, mode);
   return unreal_launch_status();
 }
 
@@ -258,10 +262,10 @@ int unreal_pc_returns(int B, int L, const int* seq_idx, const int* seq_len, cons
 }
 
 int unreal_lar_fill(int rows, int A, const int* last_action, const float* last_reward, const int* idx, float* xcat,
-                    int ld, int col0, void* stream) {
+                    int ld, int col0, int clip_reward, void* stream) {
   if (rows <= 0 || A <= 0 || ld < col0 + A + 1) return UNREAL_EINVAL;
   hipLaunchKernelGGL(lar_fill_kernel, GRID1(rows * (ld - col0)), rows, A, last_action, last_reward, idx, xcat, ld,
-                     col0);
+                     col0, clip_reward);
   return unreal_launch_status();
 }
 

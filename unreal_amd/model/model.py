@@ -191,7 +191,7 @@ class UnrealModel(object):
         self.base_lstm_state_out = (z, z.clone())     # (c, h) like LSTMStateTuple
 
     # -- batched building blocks -----------------------------------------------------------------------
-    def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True):
+    def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False):
         """conv encoder -> fc (+ last_action_reward columns and the input half of the LSTM gates) for rows
         [row0, row0+nrows) of a path workspace."""
         p = self.p
@@ -209,7 +209,7 @@ class UnrealModel(object):
         if lar_from_ring:
             ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, XLD)
         else:
-            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, XLD)
+            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, XLD, clip=clip_lar)
         ops.gemm(0, 0, nrows, 1024, 256 + A + 1, xcat, XLD, p["lstm_kernel"], 1024, ws.gates[row0 * 1024:], 1024)
 
     def lstm_step(self, ws, t, B):
@@ -228,9 +228,9 @@ class UnrealModel(object):
             return ws.h[row0 * 256:], 256
         return ws.xcat[row0 * XLD:], XLD
 
-    def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True):
+    def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False):
         """conv encoder -> fc -> (LSTM over T steps from ws.c0/ws.h0); rows = T*B listed in ws.frame_idx."""
-        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1)
+        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar)
         if self._use_lstm:
             for t in range(T):
                 self.lstm_step(ws, t, B)

@@ -139,11 +139,30 @@ def replay_sample_seq(ring, L, start_draw, seq_idx, seq_len):
           ptr(ring.r_terminal), ptr(seq_idx), ptr(seq_len))
 
 
-def replay_sample_rp(ring, coin, u, rp_idx, rp_class):
+def replay_sample_rp(ring, coin, u, rp_idx, rp_class, mode=0):
     B = ring.B
     _chk(coin, "i32", B); _chk(u, "f64", B); _chk(rp_idx, "i32", 3 * B); _chk(rp_class, "i32", B)
     _call("unreal_replay_sample_rp", B, ring.H, ring.H1, ptr(coin), ptr(u), ptr(ring.count),
-          ptr(ring.r_reward), ptr(rp_idx), ptr(rp_class))
+          ptr(ring.r_reward), ptr(rp_idx), ptr(rp_class), int(mode))
+
+
+def hostfed_step(ring, staged, actions, rewards, terminals, active=None, out_reward=None, out_terminal=None,
+                 reset_on_terminal=True, track_score=False, clip_reward=True, pc_denom=48.0 * 255.0):
+    B = ring.B
+    _chk(staged, "u8", B * FRAME_BYTES, "staged"); _chk(actions, "i32", B); _chk(rewards, "f32", B)
+    _chk(terminals, "i32", B); _chk(active, "i32", B, optional=True)
+    _chk(out_reward, "f32", B, optional=True); _chk(out_terminal, "i32", B, optional=True)
+    _call("unreal_hostfed_step", B, ring.H1, ptr(staged), ptr(actions), ptr(rewards), ptr(terminals), ptr(active),
+          ptr(ring.last_action), ptr(ring.last_reward), ptr(ring.count), ptr(ring.frames), ptr(ring.r_reward),
+          ptr(ring.r_action), ptr(ring.r_terminal), ptr(ring.r_last_action), ptr(ring.r_last_reward), ptr(ring.r_pc),
+          ptr(out_reward), ptr(out_terminal), ptr(ring.episode_reward), ptr(ring.score_out), ptr(ring.score_valid),
+          int(reset_on_terminal), int(track_score), int(clip_reward), float(pc_denom))
+
+
+def hostfed_reset(ring, staged, mask=None):
+    _chk(staged, "u8", ring.B * FRAME_BYTES, "staged"); _chk(mask, "i32", ring.B, optional=True)
+    _call("unreal_hostfed_reset", ring.B, ring.H1, ptr(mask), ptr(staged), ptr(ring.last_action),
+          ptr(ring.last_reward), ptr(ring.count), ptr(ring.frames))
 
 
 def base_returns(B, T, rewards, values, n_steps, boot_v, terminal_end, gamma, R_out, adv_out):
@@ -169,12 +188,12 @@ def pc_returns(ring, L, seq_idx, seq_len, boot_qmax, gamma_pc, R_out):
           ptr(boot_qmax), float(gamma_pc), ptr(R_out))
 
 
-def lar_fill(rows, A, last_action, last_reward, idx, xcat, ld, col0=256):
+def lar_fill(rows, A, last_action, last_reward, idx, xcat, ld, col0=256, clip=False):
     _chk(last_action, "i32"); _chk(last_reward, "f32"); _chk(idx, "i32", rows, optional=True)
     _chk(xcat, "f32", rows * ld)
     if idx is None and (last_action.numel() < rows or last_reward.numel() < rows):
         raise ValueError("lar_fill: per-row sources too short")
-    _call("unreal_lar_fill", rows, A, ptr(last_action), ptr(last_reward), ptr(idx), ptr(xcat), ld, col0)
+    _call("unreal_lar_fill", rows, A, ptr(last_action), ptr(last_reward), ptr(idx), ptr(xcat), ld, col0, int(clip))
 
 
 def gather_i32(src, idx, out):

@@ -64,9 +64,14 @@ class Trainer(object):
                  experience_history_size, max_global_time_step, device, segnet_param_dict=None,
                  image_shape=(84, 84), is_training=True, n_classes=0, random_state=None, termination_time=50.0,
                  segnet_lambda=1.0, dropout=0.0, batch_size=1, world_size=1, rank=0, seed=0xA3C, draws=None,
-                 grad_sync=None):
-        if env_type != "maze":
-            raise NotImplementedError("device actors exist for env_type='maze' only (SURVEY 8f: lab/indoor are next)")
+                 grad_sync=None, simulator=None):
+        if env_type != "maze" and simulator is None:
+            raise NotImplementedError("env_type=%r needs a host simulator object (simulator=...); only 'maze' runs "
+                                      "entirely on the device" % env_type)
+        self.simulator = simulator
+        # upstream replay semantics for host-fed (Lab-contract) actors: zero / non-zero reward buckets and reward
+        # clipping (train/experience_lab_ver.py:14,18,76-80); this fork's buckets for the maze (train/experience.py)
+        self.rp_mode = 0 if env_type == "maze" else 1
         self.thread_index = thread_index
         self.learning_rate_input = learning_rate_input
         self.env_type, self.env_name = env_type, env_name
@@ -107,7 +112,12 @@ class Trainer(object):
     def prepare(self, termination_time=50.0, termination_dist_value=-10.0):
         B, A, dev = self.B, self.action_size, self.device
         T, Ta = self.n_step_TD, self.local_t_max
-        self.environment = BatchedMazeEnvironment(B, self.experience_history_size, dev)
+        if self.env_type == "maze":
+            self.environment = BatchedMazeEnvironment(B, self.experience_history_size, dev)
+        else:
+            from ..environment.hostfed_environment import HostFedEnvironment
+            self.environment = HostFedEnvironment(self.simulator, B, self.experience_history_size, dev,
+                                                  action_size=A, clip_reward=True)
         self.ring = self.environment.ring
         self.experience = Experience(self.experience_history_size, ring=self.ring)
         lstm = self.use_lstm
@@ -215,7 +225,8 @@ class Trainer(object):
             bw.c0.copy_(self.lstm_c)
             bw.h0.copy_(self.lstm_h)
         self.ring.cur_idx(out=bw.frame_idx[:B])
-        feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=False, save_c1=False)
+        feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=False, save_c1=False,
+                                     clip_lar=self.rp_mode == 1)   # frame.get_action_reward(): stored (clipped) reward
         net.value_forward(B, feat, ld, self.boot_v)
         if self.use_lstm:                      # episode ended -> reset_state() (trainer.py:293)
             ops.reset_state(B, self.terminal_end, self.lstm_c, self.lstm_h)
@@ -308,7 +319,7 @@ class Trainer(object):
         p, g, gws = net.p, net.g, self.gws
         self.draws.randint(2, self.rp_coin)
         self.draws.uniform(self.rp_u)
-        ops.replay_sample_rp(self.ring, self.rp_coin, self.rp_u, ws.frame_idx[:3 * B], self.rp_class)
+        ops.replay_sample_rp(self.ring, self.rp_coin, self.rp_u, ws.frame_idx[:3 * B], self.rp_class, self.rp_mode)
         ops.encoder_fwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv1"],
                         p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1)
         ops.linear_small_fwd(B, 7776, 3, ws.f2, 7776, p["W_rp_fc1"], p["b_rp_fc1"], self.rp_logits, 3)
