@@ -1,0 +1,67 @@
+"""Checkpoint file protocol (CPU): naming / global_t parsing / wall_t / rotation as in the reference
+(main.py:404-419, 481-502), payload round trip, slot-restart option."""
+import os
+
+import numpy as np
+import torch
+
+from unreal_amd import checkpoint as ck
+from unreal_amd.model.model import FlatParams, param_spec
+
+
+class _Net(object):
+    def __init__(self):
+        self.spec = param_spec(4)
+        self.params = FlatParams(self.spec, "cpu")
+        self.params.flat.copy_(torch.arange(self.params.size, dtype=torch.float32) * 1e-6)
+
+    def export_named(self):
+        return {n: self.params.shaped(n).numpy().copy() for n, _, _ in self.spec}
+
+    def load_named(self, named):
+        for k, v in named.items():
+            self.params.views[k].copy_(torch.as_tensor(np.asarray(v, dtype=np.float32).reshape(-1)))
+
+
+class _Applier(object):
+    ms = mom = None
+
+    def _create_slots(self, flat):
+        if self.ms is None:
+            self.ms, self.mom = torch.ones_like(flat), torch.zeros_like(flat)
+
+
+def test_names_and_schedule():
+    assert ck.checkpoint_name(-0.123456789, 200000) == "checkpoint-123456-200000.pt"
+    assert ck.checkpoint_name(0.0, 100) == "checkpoint-0-100.pt"            # str(abs(0.0))[2:8] == '0'
+    assert ck.next_save_steps(0, 100000) == 100000 and ck.next_save_steps(250001, 100000) == 300000
+
+
+def test_round_trip_and_rotation(tmp_path):
+    d = str(tmp_path / "ckpt")
+    net, app = _Net(), _Applier()
+    app._create_slots(net.params.flat)
+    app.ms.mul_(0.5)
+    app.mom.add_(0.25)
+    for k in range(23):
+        net.params.flat.add_(1.0)
+        ck.save(d, net, app, global_t=(k + 1) * 100000, wall_t=12.5 * (k + 1), best_score=-0.5)
+    lst = ck.list_checkpoints(d)
+    assert len(lst) == 20 and lst[0][0] == 400000 and lst[-1][0] == 2300000      # max_to_keep = 20
+    assert not os.path.exists(os.path.join(d, "wall_t.100000")) and os.path.exists(os.path.join(d, "wall_t.2300000"))
+    want = net.params.flat.clone()
+    net2, app2 = _Net(), _Applier()
+    g, w, s = ck.restore(d, net2, app2)
+    assert (g, w, s) == (2300000, 12.5 * 23, -0.5)
+    assert torch.equal(net2.params.flat, want) and torch.equal(app2.ms, app.ms) and torch.equal(app2.mom, app.mom)
+    net3, app3 = _Net(), _Applier()
+    ck.restore(d, net3, app3, restore_slots=False)          # reference behaviour: slots restart
+    assert torch.equal(net3.params.flat, want) and float(app3.ms.min()) == 1.0 and float(app3.mom.abs().max()) == 0.0
+    assert ck.restore(str(tmp_path / "empty"), net3) is None
+    p = str(tmp_path / "vars.npz")
+    ck.export_npz(p, net)
+    net4 = _Net()
+    net4.params.flat.zero_()
+    ck.import_npz(p, net4)
+    for n, _, _ in net.spec:
+        assert torch.equal(net4.params.views[n], net.params.views[n])

@@ -131,7 +131,7 @@ __global__ void softmax_sample_kernel(int rows, int A, float* __restrict__ logit
   float s = 0.f;
   for (int a = 0; a < A; ++a) { float e = expf(p[a] - m); p[a] = e; s += e; }
   for (int a = 0; a < A; ++a) p[a] = p[a] / s;
-  if (action) {
+  if (action && u) {
     double tot = 0.0;
     for (int a = 0; a < A; ++a) tot += (double)p[a];
     double run = 0.0, uu = u[r];
@@ -141,6 +141,11 @@ __global__ void softmax_sample_kernel(int rows, int A, float* __restrict__ logit
       if (run / tot <= uu) act = a + 1;     // searchsorted(cdf, u, side='right')
     }
     action[r] = min(act, A - 1);
+  } else if (action) {                      // greedy (np.argmax: first maximum), for evaluation
+    int best = 0;
+    for (int a = 1; a < A; ++a)
+      if (p[a] > p[best]) best = a;
+    action[r] = best;
   }
 }
 
@@ -334,7 +339,7 @@ int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, 
 }
 
 int unreal_softmax_sample(int rows, int A, float* logits_pi, int ld, const double* u, int* action, void* stream) {
-  if (rows <= 0 || A <= 0 || A > 8 || !logits_pi || ld < A || (action && !u)) return UNREAL_EINVAL;
+  if (rows <= 0 || A <= 0 || A > 8 || !logits_pi || ld < A) return UNREAL_EINVAL;
   hipLaunchKernelGGL(softmax_sample_kernel, GRID1(rows), rows, A, logits_pi, ld, u, action);
   return unreal_launch_status();
 }

@@ -1,0 +1,74 @@
+"""Evaluation harness, after /root/reference/evaluate.py:92-169, 250-275: run the policy of a
+(restored) network WITHOUT learning for a number of episodes and report return / success statistics.  The
+reference evaluates one MINOS episode at a time with batch-1 session calls; here B maze actors roll in
+lock-step on the device with the same kernels the trainer uses (policy sampled like `choose_action`, or
+greedy).  The maze has no step limit (maze_environment.py:114-118), so `max_episode_steps` bounds an episode;
+such episodes count as failures ("success := terminal")."""
+import torch
+
+from . import ops
+from .environment.maze_environment import BatchedMazeEnvironment
+from .model.model import PathWS
+from .train.trainer import PhiloxDraws
+
+
+class Evaluate(object):
+    def __init__(self, network, batch_size=64, device="cuda:0", seed=0xE7A1, greedy=False, draws=None):
+        self.net, self.B, self.greedy = network, int(batch_size), greedy
+        self.device = torch.device(device)
+        self.draws = draws if draws is not None else PhiloxDraws(seed)
+        B, A = self.B, network._action_size
+        self.env = BatchedMazeEnvironment(B, 2, self.device)
+        self.ws = PathWS(B, B, self.device, save_c1=False, lstm=network._use_lstm)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)
+        self.pi, self.v = z(B * A, torch.float32), z(B, torch.float32)
+        self.u, self.actions = z(B, torch.float64), z(B, torch.int32)
+        self.rewards, self.terminals = z(B, torch.float32), z(B, torch.int32)
+
+    def process(self, n_episodes, max_episode_steps=2000):
+        """-> dict(episodes, success_rate, mean_return, mean_length, timeouts)"""
+        B, A, net, ws, ring = self.B, self.net._action_size, self.net, self.ws, self.env.ring
+        self.env.reset()
+        ring.episode_reward.zero_()
+        if net._use_lstm:
+            ws.c0.zero_()
+            ws.h0.zero_()
+        steps = [0] * B
+        done, returns, lengths, successes, timeouts = 0, [], [], 0, 0
+        while done < n_episodes:
+            ring.cur_idx(out=ws.frame_idx[:B])
+            net.encode_rows(ring, ws, 0, B, lar_from_ring=False, save_c1=False)
+            if net._use_lstm:
+                net.lstm_step(ws, 0, B)
+            feat, ld = net.features(ws, 0)
+            net.heads_forward(B, feat, ld, self.pi, self.v)
+            if self.greedy:
+                ops.softmax_sample(B, A, self.pi, A, None, self.actions)
+            else:
+                self.draws.uniform(self.u)
+                ops.softmax_sample(B, A, self.pi, A, self.u, self.actions)
+            self.env.process(self.actions, None, self.rewards, self.terminals, reset_on_terminal=True,
+                             track_score=True)
+            if net._use_lstm:                      # carry the state; zero it where the episode ended
+                ws.c0.copy_(ws.c[:B * 256])
+                ws.h0.copy_(ws.h[:B * 256])
+                ops.reset_state(B, self.terminals, ws.c0, ws.h0)
+            term = self.terminals.cpu().numpy()
+            score = ring.score_out.cpu().numpy()
+            force = torch.zeros(B, dtype=torch.int32)
+            for b in range(B):
+                steps[b] += 1
+                if term[b]:
+                    returns.append(float(score[b])); lengths.append(steps[b]); successes += 1; done += 1; steps[b] = 0
+                elif steps[b] >= max_episode_steps:
+                    timeouts += 1; done += 1; steps[b] = 0; force[b] = 1
+                    returns.append(float(ring.episode_reward.cpu()[b])); lengths.append(max_episode_steps)
+            if int(force.sum()):                   # abandon timed-out episodes
+                m = force.to(self.device)
+                self.env.reset(m)
+                ring.episode_reward.mul_((1 - m).to(torch.float32))
+                if net._use_lstm:
+                    ops.reset_state(B, m, ws.c0, ws.h0)
+        n = len(returns)
+        return dict(episodes=n, success_rate=successes / float(n), mean_return=sum(returns) / n,
+                    mean_length=sum(lengths) / float(n), timeouts=timeouts)
