@@ -354,20 +354,22 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
   for (int e = gtid; e < 3 * D2_LD; e += 256) d2[C2_POS * D2_LD + e] = 0.f;   // zero rows 81..83
 
   f32x4 aw2[4][2];      // dW2 tiles: ky = gw, kx = 0..3, nt = 0..1
-  f32x4 aw1[3];         // dW1 tiles: mt = 3*gw + 0..2
+  f32x4 aw1[3][4];      // dW1 tiles (g,t): patch elements m = 64g + 4*row + t, all 12 tiles, THIS wave's 100 positions
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) aw2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 3; ++a) aw1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) aw1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // n = (gtid % 8) * 4 + e
   float adb1 = 0.f;                       // channel i
 
-  int off1[3];
+  int off1[3];          // byte offset of patch element m = 64g + 4i in the 8x8x3 patch (4 consecutive m = one dword)
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    int m = (3 * gw + a) * 16 + i;
+    int m = 64 * a + 4 * i;
     off1[a] = (m / 24) * FRAME_ROW_BYTES + (m % 24);
   }
 
@@ -469,40 +471,59 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
       }
     }
     if (valid && (PHASES & 4)) {
-      // (3) conv1 wgrad.  Positions kp = 20*sy + 4*s5 + q: all addresses are linear in (sy, s5) -> immediates +
-      // one add per row.  One row of operands (5 steps) is read ahead of the row being multiplied.
-      const uint8_t* fa0 = fr + 12 * q + off1[0];
-      const uint8_t* fa1 = fr + 12 * q + off1[1];
-      const uint8_t* fa2 = fr + 12 * q + off1[2];
-      const float* dp = c1 + q * C1_LD + i;
-      float bc[5], ac[5][3];
+      // (3) conv1 wgrad as EXACT-PRODUCT bf16 MFMAs (same argument as the forward conv1): A = uint8 pixels
+      // (exact in bf16), B = d1 split into three bf16 terms (hi/mid/lo by truncation, residuals exact), three
+      // v_mfma_f32_16x16x32_bf16 per 32-position chunk, fp32 accumulation.  K (positions) is split over the 4 waves:
+      // wave gw owns output rows 5gw..5gw+4 (100 positions = 4 chunks of 32 slots, 28 of them zero padding) and ALL
+      // 12 row tiles; tile (g,t) holds patch elements m = 64g + 4*row + t so one aligned dword of the frame per
+      // position feeds 4 tiles.  Lane (i, q) supplies slots s = 32kc + 8q + j, j = 0..7, of row i (A) / channel i (B).
+      const uint8_t* frow = fr + (4 * 5 * gw) * FRAME_ROW_BYTES;
+#pragma unroll 1
+      for (int kc = 0; kc < 4; ++kc) {
+        u32x4 bpl[3];
+        {
+          uint32_t t0[8], t1[8], t2[8];
 #pragma unroll
-      for (int s5 = 0; s5 < 5; ++s5) {
-        bc[s5] = dp[4 * s5 * C1_LD];
-        ac[s5][0] = (float)fa0[48 * s5]; ac[s5][1] = (float)fa1[48 * s5]; ac[s5][2] = (float)fa2[48 * s5];
-      }
-      for (int sy = 0; sy < 20; ++sy) {
-        fa0 += 4 * FRAME_ROW_BYTES; fa1 += 4 * FRAME_ROW_BYTES; fa2 += 4 * FRAME_ROW_BYTES;
-        dp += 20 * C1_LD;
-        float bn[5], an[5][3];
-        if (sy + 1 < 20) {
+          for (int j = 0; j < 8; ++j) {
+            const int sl = 32 * kc + 8 * q + j;
+            const float v = sl < 100 ? c1[(100 * gw + sl) * C1_LD + i] : 0.f;
+            t0[j] = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(t0[j]);
+            t1[j] = __float_as_uint(r1) & 0xffff0000u;
+            t2[j] = __float_as_uint(r1 - __uint_as_float(t1[j]));     // <= 8 significant bits left: exact in bf16
+          }
 #pragma unroll
-          for (int s5 = 0; s5 < 5; ++s5) {
-            bn[s5] = dp[4 * s5 * C1_LD];
-            an[s5][0] = (float)fa0[48 * s5]; an[s5][1] = (float)fa1[48 * s5]; an[s5][2] = (float)fa2[48 * s5];
+          for (int e = 0; e < 4; ++e) {
+            bpl[0][e] = __builtin_amdgcn_perm(t0[2 * e + 1], t0[2 * e], 0x07060302u);
+            bpl[1][e] = __builtin_amdgcn_perm(t1[2 * e + 1], t1[2 * e], 0x07060302u);
+            bpl[2][e] = __builtin_amdgcn_perm(t2[2 * e + 1], t2[2 * e], 0x07060302u);
           }
         }
+        int pofs[8];
 #pragma unroll
-        for (int s5 = 0; s5 < 5; ++s5) {
-          aw1[0] = MFMA16(ac[s5][0], bc[s5], aw1[0]);
-          aw1[1] = MFMA16(ac[s5][1], bc[s5], aw1[1]);
-          aw1[2] = MFMA16(ac[s5][2], bc[s5], aw1[2]);
+        for (int j = 0; j < 8; ++j) {
+          const int sl = min(32 * kc + 8 * q + j, 99);                // padding slots: any valid address (B = 0)
+          pofs[j] = (4 * (sl / 20)) * FRAME_ROW_BYTES + 12 * (sl % 20);
         }
-        if (sy + 1 < 20) {
 #pragma unroll
-          for (int s5 = 0; s5 < 5; ++s5) {
-            bc[s5] = bn[s5];
-            ac[s5][0] = an[s5][0]; ac[s5][1] = an[s5][1]; ac[s5][2] = an[s5][2];
+        for (int g = 0; g < 3; ++g) {
+          uint32_t w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const uint32_t*>(frow + pofs[j] + off1[g]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float f0 = (float)((w[2 * e] >> (8 * t)) & 0xffu);
+              const float f1 = (float)((w[2 * e + 1] >> (8 * t)) & 0xffu);
+              pk[e] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+            }
+            const bf16x8 av = __builtin_bit_cast(bf16x8, pk);
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+              aw1[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bpl[tm]), aw1[g][t],
+                                                                  0, 0, 0);
           }
         }
       }
@@ -540,9 +561,12 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
       for (int r = 0; r < 4; ++r)
         atomicAdd(dW2 + ((gw * 4 + kx) * 16 + 4 * q + r) * 32 + nt * 16 + i, aw2[kx][nt][r]);
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW1 + ((3 * gw + a) * 16 + 4 * q + r) * 16 + i, scale * aw1[a][r]);
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dW1 + (64 * g + 4 * (4 * q + r) + t) * 16 + i, scale * aw1[g][t][r]);
   // db1: lanes with equal i (channel) across q
   adb1 += __shfl_xor(adb1, 16, 64);
   adb1 += __shfl_xor(adb1, 32, 64);
