@@ -103,6 +103,19 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
 int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                     int ldb, float* C, int ldc, const float* bias, const float* mask, int ldm, int flags,
                     int splitk, void* stream);
+/* C = A[M,K] * W[N,K]^T with fp32-grade error on the bf16 matrix cores: every operand element is split into three
+ * bf16 terms (exact residuals) and six term-pair MFMAs are accumulated in fp32 (csrc/gemm_split.hip).  A is fp32;
+ * W3 is the weight matrix as a pre-split shadow made by unreal_split_bf16x3: plane t at W3 + t*plane_stride, row n
+ * at + n*ldw (ldw a multiple of 8 and >= K rounded up to 32, padding zero).  Same epilogue flags as
+ * unreal_gemm_f32 except ATOMIC.  Used for the forward and dgrad GEMMs of the dense layers. */
+int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw,
+                             long plane_stride, float* C, int ldc, const float* bias, const float* mask, int ldm,
+                             int flags, void* stream);
+/* bf16x3 shadow of a weight matrix src[rows][cols]: dst[t][r][c] (transpose = 0) or dst[t][c][r] (transpose = 1),
+ * t = 0..2 the bf16 terms (sum of the three == src to 2^-24 relative).  dst padding is left untouched (zero it once).
+ * Refreshed after every RMSProp step / checkpoint restore. */
+int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, uint16_t* dst, int ld_dst,
+                        long plane_stride, void* stream);
 int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
                           float* c_out, float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,

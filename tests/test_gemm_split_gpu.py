@@ -1,0 +1,53 @@
+"""Split-operand (3 x bf16) GEMM: fp32-grade numerics at the SAME tolerance as the fp32-MFMA GEMM, plus an error
+comparison against the fp32 kernel on identical data (the split kernel must not be worse than 2x)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 2592), (200, 1024, 261), (4096, 256, 512), (7, 5, 3), (130, 2592, 256),
+                                   (33, 261, 1024), (640, 384, 96)])
+def test_split_gemm_matches_fp64(M, N, K):
+    from unreal_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    lda, ldb, ldc = (K + 7) // 4 * 4, (K + 11) // 4 * 4, N + 3
+    A = rs.uniform(-1, 1, size=(M, lda)); B = rs.uniform(-1, 1, size=(N, ldb))
+    A[:, :K] *= rs.choice([1.0, 1e-3, 37.0], size=(M, 1))         # mixed magnitudes
+    bias = rs.uniform(-1, 1, size=N)
+    ref = A[:, :K] @ B[:, :K].T
+    scale = np.abs(A[:, :K]) @ np.abs(B[:, :K]).T                 # sum |a||b| per output
+    C = torch.full((M, ldc), 7.0, device=DEV)
+    Bd = dev(B)
+    W = ops.SplitWeights(Bd, N, K, ldb, transpose=False)
+    Wt = ops.SplitWeights(dev(B[:, :K].T), K, N, N, transpose=True)          # same matrix from its transpose
+    assert torch.equal(W.planes, Wt.planes)
+    pl = W.planes.view(torch.bfloat16).view(3, N, W.ldw).double().cpu().numpy()
+    np.testing.assert_array_equal(pl[:, :, K:], 0)
+    Bf = B[:, :K].astype(np.float32).astype(np.float64)
+    assert np.abs(pl.sum(0)[:, :K] - Bf).max() <= 2.0 ** -23 * np.abs(Bf).max()   # the three terms rebuild the fp32 value
+    ops.gemm_split_nt(M, N, K, dev(A), lda, W, C, ldc, bias=dev(bias))
+    got = C[:, :N].cpu().double().numpy()
+    err = np.abs(got - (ref + bias))
+    assert (err <= 3e-7 * scale + 1e-6).all(), (err / (scale + 1e-30)).max()
+    assert float(C[:, N:].min()) == 7.0
+    # same data through the fp32-MFMA kernel: the split kernel's error is of the same size
+    C32 = torch.zeros(M, ldc, device=DEV)
+    ops.gemm(0, 1, M, N, K, dev(A), lda, dev(B), ldb, C32, ldc, bias=dev(bias))
+    err32 = np.abs(C32[:, :N].cpu().double().numpy() - (ref + bias))
+    assert np.sqrt((err ** 2).mean()) <= 2.0 * np.sqrt((err32 ** 2).mean()) + 1e-9, (err.mean(), err32.mean())
+    # flags
+    C0 = rs.uniform(-1, 1, size=(M, ldc)); msk = rs.uniform(-1, 1, size=(M, N))
+    Cx = dev(C0)
+    ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, flags=ops.GEMM_ACCUM | ops.GEMM_RELU)
+    want = np.maximum(ref + C0[:, :N], 0)
+    assert (np.abs(Cx[:, :N].cpu().double().numpy() - want) <= 3e-7 * scale + 2e-6).all()
+    Cx = torch.zeros(M, ldc, device=DEV)
+    ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, mask=dev(msk), ldm=N, flags=ops.GEMM_RELU_MASK)
+    assert (np.abs(Cx[:, :N].cpu().double().numpy() - ref * (msk > 0)) <= 3e-7 * scale + 1e-6).all()

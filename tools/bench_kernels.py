@@ -74,6 +74,16 @@ def main():
     gemm_case("NT d_feat_pc", 0, 1, R, 256, 2592)
     gemm_case("NT dh_rec_step", 0, 1, B, 256, 1024)
 
+    if not FILT or FILT in "split gemm":
+        for name, M, N, K in (("fc_fwd", R, 256, 2592), ("lstm_x", R, 1024, 261), ("pc_fc1", R, 2592, 256),
+                              ("d_fc", R, 256, 1024), ("d_f2", R, 2592, 256), ("fc_roll", B, 256, 2592),
+                              ("lstm_h_step", B, 1024, 256), ("dh_rec_step", B, 256, 1024)):
+            lda = (K + 3) // 4 * 4
+            A_ = rnd(M * lda); Bt_ = ops.SplitWeights(rnd(N * K), N, K, K, False); C_ = torch.zeros(M * N, device=DEV)
+            report("split_nt %s M=%d N=%d K=%d" % (name, M, N, K),
+                   timeit(lambda: ops.gemm_split_nt(M, N, K, A_, lda, Bt_, C_, N)), flop=2.0 * M * N * K)
+            del A_, Bt_, C_
+
     if not FILT or FILT in "encoder":
         for N in (R, B):
             pool = torch.randint(0, 2, (N * ops.FRAME_BYTES,), dtype=torch.uint8, device=DEV)

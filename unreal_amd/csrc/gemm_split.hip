@@ -1,0 +1,342 @@
+// fp32-equivalent GEMM on the bf16 matrix cores of gfx950 ("split-operand", 3 x bf16):
+//
+//   C[M,N] = A[M,K] * W[N,K]^T (+ bias) (ReLU) (ReLU-mask) (accumulate)
+//
+// A is an fp32 activation matrix (k contiguous).  W is a WEIGHT matrix that the host keeps as a pre-split shadow:
+// three bf16 planes W = W1 + W2 + W3 (round-to-nearest at each level, residuals exact in fp32: 8+8+8 mantissa
+// bits), rows zero-padded to a multiple of 32 k (unreal_split_bf16x3, refreshed after every optimiser step).  A's
+// tile is split the same way when it is staged into LDS.  Each 32x32x16 product tile is accumulated in fp32 from
+// the six term pairs whose weight is >= 2^-16:
+//   a1b1, a1b2, a2b1, a1b3, a2b2, a3b1          (v_mfma_f32_32x32x16_bf16, exact bf16 x bf16 products)
+// The dropped pairs (a2b3, a3b2, a3b3) are below 2^-25 |ab| with random sign, i.e. under the rounding error of the
+// fp32 product they replace, so the result carries fp32-grade error (parity tests use the SAME tolerance as the
+// fp32-MFMA kernel of gemm.hip, and compare the two kernels' errors on the same data).
+// Used for the forward and dgrad GEMMs of /root/reference/model/model.py:314,334,423 + BasicLSTMCell (model.py:110);
+// wgrad (both operands activations, k-major) stays on the fp32 MFMA path of gemm.hip.
+//
+// Layout: 128x128x32 (or 64x64x32) block tile, 4 waves as 2x2.  LDS image per operand: [plane(3)][row][k(32) bf16]
+// with 80-byte rows (ds_read_b128 fragment reads are conflict-free).  One LDS buffer; the next K tile travels in
+// registers and is split/stored between the two barriers while the second half of the current tile's MFMAs runs.
+// Blocks are numbered so that the column blocks sharing one A row panel run back-to-back on ONE XCD (its L2 then
+// serves the re-reads; with the default order they land on 8 different L2s and A is fetched from HBM 2..8 times).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int ROW_B = 80;                    // bytes per LDS row: 32 bf16 + 16 pad
+constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_RELU_MASK = 8;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef SPLIT_ABLATE
+#define SPLIT_ABLATE 0      // tools/exp/split_ablate.py: 1 no global loads in the loop, 2 no split/store, 4 no MFMA,
+                            // 8 every block reads the same 8 rows of A (cache hits)
+#endif
+
+struct SplitArgs {
+  int M, N, K;
+  const float* A; int lda;
+  const unsigned short* W; int ldw; long plane;     // bf16 planes: W + t*plane + n*ldw + k
+  float* C; int ldc;
+  const float* bias;
+  const float* mask; int ldm;
+  int flags;
+  int vecA;
+  int nbx, nby;
+};
+
+// One 16-byte piece of the A tile per call (piece p of ROWS*BK/1024).  Branch-free on purpose: rows past the end
+// re-read the last valid row (their C rows are never stored); a vector that would start past the row is pulled back
+// inside it and k >= K is zeroed when the piece is split (a_piece_store), so any lda >= K works.  Divergent or even
+// uniform branches here break the K loop into several basic blocks and the MFMA / VALU / load interleave is lost
+// (with divergent ones the compiler also serialises the loads with s_waitcnt vmcnt(0)).
+template <int ROWS, bool VEC>
+__device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int ld, int rows_total, int K, int r0, int k0, int p) {
+  const int id = threadIdx.x + 256 * p;
+  const int r = (SPLIT_ABLATE & 8) ? (id / (BK / 4)) & 7 : min(r0 + id / (BK / 4), rows_total - 1);
+  const int k = k0 + (id % (BK / 4)) * 4;
+  const float* row = P + (size_t)r * ld;
+  if (VEC) return *reinterpret_cast<const f32x4*>(row + min(k, ld - 4));
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = row[min(k + e, K - 1)];
+  return v;
+}
+
+// split 4 consecutive-k fp32 values into three bf16 planes and store 8 bytes per plane; klim = K - k0 of that tile
+template <int ROWS>
+__device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p) {
+  const int id = threadIdx.x + 256 * p;
+  const int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? v[e] : 0.f;
+  f32x2 x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
+  u32x2 pl[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const bf16x2 h01 = __builtin_convertvector(x01, bf16x2), h23 = __builtin_convertvector(x23, bf16x2);
+    pl[t] = (u32x2){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    if (t < 2) {
+      x01 = x01 - __builtin_convertvector(h01, f32x2);
+      x23 = x23 - __builtin_convertvector(h23, f32x2);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    *reinterpret_cast<u32x2*>(S + (t * ROWS + r) * ROW_B + k * 2) = pl[t];
+}
+
+// weight tile piece: 3 planes x ROWS rows x 64 B, 16 B per lane (planes are zero-padded in k, rows clamped)
+template <int ROWS>
+__device__ __forceinline__ u32x4 w_piece_load(const unsigned short* __restrict__ W, int ldw, long plane, int rows_total,
+                                              int r0, int k0, int p) {
+  const int id = threadIdx.x + 256 * p;
+  const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
+  const int row = min(r0 + r, rows_total - 1);
+  return *reinterpret_cast<const u32x4*>(W + t * plane + (size_t)row * ldw + k0 + c * 8);
+}
+
+template <int ROWS>
+__device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p) {
+  const int id = threadIdx.x + 256 * p;
+  const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
+  *reinterpret_cast<u32x4*>(S + (t * ROWS + r) * ROW_B + c * 16) = v;
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void read_frags(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int li, int kh,
+                                           int ks, bf16x8 (&af)[BM / 64][3], bf16x8 (&bf)[BN / 64][3]) {
+#pragma unroll
+  for (int i = 0; i < BM / 64; ++i)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      af[i][t] = *reinterpret_cast<const bf16x8*>(As + (t * BM + wm * (BM / 2) + i * 32 + li) * ROW_B + (16 * ks + 8 * kh) * 2);
+#pragma unroll
+  for (int j = 0; j < BN / 64; ++j)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      bf[j][t] = *reinterpret_cast<const bf16x8*>(Bs + (t * BN + wn * (BN / 2) + j * 32 + li) * ROW_B + (16 * ks + 8 * kh) * 2);
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x8 (&bf)[TN][3], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x16 c = acc[i][j];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], c, 0, 0, 0);   // smallest terms first
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+}
+
+template <int BM, int BN, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int PA = BM * BK / 1024, PW = 3 * BN / 64;
+  constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
+  constexpr int C_BYTES = BM * (BN + 4) * 4;
+  constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + A_BYTES;
+
+  // XCD-aware block order: workgroup L runs on XCD L % 8; slot s = L / 8 of that XCD sweeps x first, and the row
+  // panels are dealt to the XCDs round-robin, so the nbx blocks that share one A panel follow each other on one L2.
+  const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+  const int bx = s % p.nbx, by = (s / p.nbx) * 8 + xcd;
+  if (by >= p.nby) return;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int nkt = (p.K + BK - 1) / BK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[PA];
+  u32x4 rw[PW];
+  const int shift = (int)((unsigned)by * 7u % (unsigned)nkt);    // de-synchronise the panel sweeps of different rows
+#define KT_AT(i) (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift)
+  {
+    const int k0 = KT_AT(0) * BK;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k0, q);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[q], p.K - k0, q);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q);
+    const int k1 = KT_AT(min(1, nkt - 1)) * BK;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k1, q);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nkt; ++it) {
+    bf16x8 af[TM][3], bf[TN][3];
+    if (!(SPLIT_ABLATE & 4)) {
+      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 0, af, bf);
+      mma_frags<TM, TN>(af, bf, acc);
+      // second half: fragments are read before the barrier, the MFMAs run after it next to the split of the next tile
+      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 1, af, bf);
+    }
+    __syncthreads();                                   // every wave has read tile `it`
+    // Tile it+1 leaves the registers (split, LDS store) and tile it+2 is fetched into them, piece by piece, next to
+    // the second-half MFMAs: loads spread between MFMAs keep the CU's vector-memory queue short (8 waves issuing 10
+    // loads each at once stall at issue, and the in-order MFMAs behind them with it).  The fetch then has a whole
+    // iteration to land.  Everything here is unconditional -- the last passes re-store / re-fetch a valid tile that
+    // is never read -- so that the section stays ONE basic block and the compiler interleaves it (explicit
+    // sched_group_barrier pipelines measured 5-10 % slower than its own schedule).
+    const int kcur = KT_AT(min(it + 1, nkt - 1)) * BK, knext = KT_AT(min(it + 2, nkt - 1)) * BK;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      if (!(SPLIT_ABLATE & 2) || it == 0) a_piece_store<BM>(As, ra[q], p.K - kcur, q);
+      if (!(SPLIT_ABLATE & 1)) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, knext, q);
+    }
+#pragma unroll
+    for (int q = 0; q < PW; ++q) {
+      if (!(SPLIT_ABLATE & 2) || it == 0) w_piece_store<BN>(Bs, rw[q], q);
+      if (!(SPLIT_ABLATE & 1)) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, knext, q);
+    }
+    if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);
+    __syncthreads();                                   // tile `it + 1` is visible
+  }
+
+  // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip)
+  constexpr int CLD = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
+  __syncthreads();
+  const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
+                    (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
+                    (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
+  constexpr int CV = BN / 4;
+  for (int id = threadIdx.x; id < BM * CV; id += 256) {
+    const int r = id / CV, c4 = (id % CV) * 4;
+    const int row = m0 + r, col = n0 + c4;
+    if (row >= p.M || col >= p.N) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+    float* cp = p.C + (size_t)row * p.ldc + col;
+    if (vecC && col + 3 < p.N) {
+      if (p.bias) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col); v += b4; }
+      if (p.flags & FLAG_ACCUM) v += *reinterpret_cast<const f32x4*>(cp);
+      if (p.flags & FLAG_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.flags & FLAG_RELU_MASK) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.ldm + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = m4[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(cp) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (col + e >= p.N) break;
+        float x = v[e] + (p.bias ? p.bias[col + e] : 0.f);
+        if (p.flags & FLAG_ACCUM) x += cp[e];
+        if (p.flags & FLAG_RELU) x = fmaxf(x, 0.f);
+        if (p.flags & FLAG_RELU_MASK) x = (p.mask[(size_t)row * p.ldm + col + e] > 0.f) ? x : 0.f;
+        cp[e] = x;
+      }
+    }
+  }
+}
+
+// weights -> bf16x3 planes: dst[t][r][c] = term_t(src[r][c]) (transpose = 0) or dst[t][c][r] (transpose = 1);
+// 32x32 tiles through LDS so both sides stay coalesced.  Padding columns of dst are left as the caller zeroed them.
+__global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, const float* __restrict__ src, int ld_src,
+                                                           int transpose, unsigned short* __restrict__ dst, int ld_dst,
+                                                           long plane) {
+  __shared__ float t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int y = ty; y < 32; y += 8)
+    if (r0 + y < rows && c0 + tx < cols) t[y][tx] = src[(size_t)(r0 + y) * ld_src + c0 + tx];
+  __syncthreads();
+  for (int y = ty; y < 32; y += 8) {
+    const int orow = transpose ? c0 + y : r0 + y, ocol = transpose ? r0 + tx : c0 + tx;
+    const bool ok = transpose ? (c0 + y < cols && r0 + tx < rows) : (r0 + y < rows && c0 + tx < cols);
+    if (!ok) continue;
+    float x = transpose ? t[tx][y] : t[y][tx];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const __bf16 h = (__bf16)x;
+      dst[k * plane + (size_t)orow * ld_dst + ocol] = __builtin_bit_cast(unsigned short, h);
+      x -= (float)h;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw, long plane_stride,
+                             float* C, int ldc, const float* bias, const float* mask, int ldm, int flags, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W3 || !C) return UNREAL_EINVAL;
+  const int kpad = (K + BK - 1) / BK * BK;
+  if (lda < K || ldw < kpad || (ldw & 7) || (plane_stride & 7) || plane_stride < (long)N * ldw || ldc < N ||
+      (((uintptr_t)W3) & 15))
+    return UNREAL_EINVAL;
+  if (flags & ~(FLAG_RELU | FLAG_ACCUM | FLAG_RELU_MASK)) return UNREAL_EINVAL;
+  if ((flags & FLAG_RELU_MASK) && (!mask || ldm < N)) return UNREAL_EINVAL;
+  SplitArgs a;
+  a.M = M; a.N = N; a.K = K;
+  a.A = A; a.lda = lda; a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = C; a.ldc = ldc;
+  a.bias = bias; a.mask = mask; a.ldm = ldm; a.flags = flags;
+  a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
+  const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (blocks128 >= 384) {
+    a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
+    const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
+    const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return unreal_launch_status();
+}
+
+int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, uint16_t* dst, int ld_dst,
+                        long plane_stride, void* stream) {
+  if (rows <= 0 || cols <= 0 || !src || !dst || ld_src < cols) return UNREAL_EINVAL;
+  const int orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
+  if (ld_dst < ocols || plane_stride < (long)orows * ld_dst) return UNREAL_EINVAL;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, src, ld_src, transpose,
+                     dst, ld_dst, plane_stride);
+  return unreal_launch_status();
+}
+
+}  // extern "C"

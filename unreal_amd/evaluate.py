@@ -28,6 +28,7 @@ class Evaluate(object):
     def process(self, n_episodes, max_episode_steps=2000):
         """-> dict(episodes, success_rate, mean_return, mean_length, timeouts)"""
         B, A, net, ws, ring = self.B, self.net._action_size, self.net, self.ws, self.env.ring
+        net.refresh_shadows()
         self.env.reset()
         ring.episode_reward.zero_()
         if net._use_lstm:

@@ -147,6 +147,38 @@ class UnrealModel(object):
         self.total_loss = self.base_loss = self.policy_loss = self.value_loss = None
         self.entropy = self.pc_loss = self.vr_loss = self.rp_loss = None
         self._b1 = None
+        self._shadow = None
+
+    # -- bf16x3 weight shadows (W operand of ops.gemm_split_nt) ---------------------------------------
+    def refresh_shadows(self):
+        """Re-split the dense-layer weights into the bf16x3 planes the split-operand GEMM multiplies by (forward:
+        transposed, dgrad: natural layout).  Cheap (a few MB); called at the start of every Trainer.process /
+        Evaluate.process / batch-1 runner, i.e. after any optimiser step, load or restore."""
+        if self._shadow is None:
+            p, A = self.p, self._action_size
+            K_x = 256 + A + 1
+            S = ops.SplitWeights
+            sh = dict(fc1_fwd=S(p["W_base_fc1"], 2592, 256, 256, True),
+                      fc1_dgrad=S(p["W_base_fc1"], 2592, 256, 256, False))
+            if self._use_lstm:
+                W = p["lstm_kernel"]
+                sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
+                          lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024),
+                          lstm_h_dgrad=S(W, 256, 1024, 1024, False, offset=K_x * 1024),
+                          lstm_fc_dgrad=S(W, 256, 1024, 1024, False))
+            if self._use_pixel_change:
+                sh.update(pc_fc1_fwd=S(p["W_pc_fc1"], 256, 2592, 2592, True),
+                          pc_fc1_dgrad=S(p["W_pc_fc1"], 256, 2592, 2592, False))
+            self._shadow = sh
+            return
+        for w in self._shadow.values():
+            w.refresh()
+
+    @property
+    def shadow(self):
+        if self._shadow is None:
+            self.refresh_shadows()
+        return self._shadow
 
     # -- parameters ---------------------------------------------------------------------------------
     def _init_weights(self, seed):
@@ -201,8 +233,9 @@ class UnrealModel(object):
         c1 = ws.c1[row0 * ops.C1_DIM:] if (save_c1 and ws.c1 is not None) else None
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
                         p["W_base_conv2"], p["b_base_conv2"], f2, c1)
-        ops.gemm(0, 0, nrows, 256, 2592, f2, 2592, p["W_base_fc1"], 256, xcat, XLD, bias=p["b_base_fc1"],
-                 flags=ops.GEMM_RELU)
+        sh = self.shadow
+        ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, XLD, bias=p["b_base_fc1"],
+                          flags=ops.GEMM_RELU)
         if not self._use_lstm:
             return
         A = self._action_size
@@ -210,16 +243,15 @@ class UnrealModel(object):
             ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, XLD)
         else:
             ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, XLD, clip=clip_lar)
-        ops.gemm(0, 0, nrows, 1024, 256 + A + 1, xcat, XLD, p["lstm_kernel"], 1024, ws.gates[row0 * 1024:], 1024)
+        ops.gemm_split_nt(nrows, 1024, 256 + A + 1, xcat, XLD, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
 
     def lstm_step(self, ws, t, B):
         """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math)."""
         p = self.p
-        Wh = p["lstm_kernel"][(256 + self._action_size + 1) * 1024:]
         h_prev = ws.h0 if t == 0 else ws.h[(t - 1) * B * 256:]
         c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
         g_t = ws.gates[t * B * 1024:]
-        ops.gemm(0, 0, B, 1024, 256, h_prev, 256, Wh, 1024, g_t, 1024, flags=ops.GEMM_ACCUM)
+        ops.gemm_split_nt(B, 1024, 256, h_prev, 256, self.shadow["lstm_h_fwd"], g_t, 1024, flags=ops.GEMM_ACCUM)
         ops.lstm_gates_fwd(B, g_t, p["lstm_bias"], c_prev, g_t, ws.c[t * B * 256:], ws.h[t * B * 256:])
 
     def features(self, ws, row0=0):
@@ -238,7 +270,7 @@ class UnrealModel(object):
 
     def trunk_backward(self, ring, ws, gws, T, B, d_feat, h0_nonzero=False):
         """Back-propagate d_feat [T*B,256] through LSTM, fc and the conv encoder into self.g."""
-        p, g = self.p, self.g
+        p, g, sh = self.p, self.g, self.shadow
         rows = T * B
         if self._use_lstm:
             A = self._action_size
@@ -252,7 +284,7 @@ class UnrealModel(object):
                                    ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:],
                                    gws.d_gates[t * B * 1024:])
                 if t > 0:
-                    ops.gemm(0, 1, B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, Wh, 1024, gws.dh_rec, 256)
+                    ops.gemm_split_nt(B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, sh["lstm_h_dgrad"], gws.dh_rec, 256)
             dW = g["lstm_kernel"]
             # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
             # last_action_reward rows by the small-N outer-product kernel (no padded third tile)
@@ -268,8 +300,8 @@ class UnrealModel(object):
                 ops.gemm(1, 0, 256, 1024, B, ws.h0, 256, gws.d_gates, 1024, dW[K_x * 1024:], 1024,
                          flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, B))
             ops.colsum(rows, 1024, gws.d_gates, 1024, g["lstm_bias"])
-            ops.gemm(0, 1, rows, 256, 1024, gws.d_gates, 1024, W, 1024, gws.d_fc, 256, mask=ws.xcat, ldm=XLD,
-                     flags=ops.GEMM_RELU_MASK)
+            ops.gemm_split_nt(rows, 256, 1024, gws.d_gates, 1024, sh["lstm_fc_dgrad"], gws.d_fc, 256, mask=ws.xcat,
+                              ldm=XLD, flags=ops.GEMM_RELU_MASK)
             d_fc = gws.d_fc
         else:
             ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, XLD)
@@ -277,8 +309,8 @@ class UnrealModel(object):
         ops.gemm(1, 0, 2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256, flags=ops.GEMM_ATOMIC,
                  splitk=_splitk(2592, 256, rows))
         ops.colsum(rows, 256, d_fc, 256, g["b_base_fc1"])
-        ops.gemm(0, 1, rows, 2592, 256, d_fc, 256, p["W_base_fc1"], 256, gws.d_f2, 2592, mask=ws.f2, ldm=2592,
-                 flags=ops.GEMM_RELU_MASK)
+        ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
+                          flags=ops.GEMM_RELU_MASK)
         ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,
                         g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
 
@@ -293,8 +325,8 @@ class UnrealModel(object):
 
     def pc_head_forward(self, rows, feat, ld, hp):
         p = self.p
-        ops.gemm(0, 0, rows, 2592, 256, feat, ld, p["W_pc_fc1"], 2592, hp, 2592, bias=p["b_pc_fc1"],
-                 flags=ops.GEMM_RELU)
+        ops.gemm_split_nt(rows, 2592, 256, feat, ld, self.shadow["pc_fc1_fwd"], hp, 2592, bias=p["b_pc_fc1"],
+                          flags=ops.GEMM_RELU)
 
     # -- reference batch-1 runners (model.py:630-728) ---------------------------------------------------
     def _b1_ws(self):
@@ -323,6 +355,7 @@ class UnrealModel(object):
         return ring, ws
 
     def _run_trunk1(self, s_t, last_action_reward, state):
+        self.refresh_shadows()                 # the caller may have changed the weights since the last call
         ring, ws = self._stage([s_t['image']], last_action_reward)
         scale = self.frame_scale
         self.frame_scale = 1.0 / 255.0

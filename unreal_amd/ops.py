@@ -14,7 +14,7 @@ F2_DIM = 2592
 C1_DIM = 6400
 GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC, GEMM_RELU_MASK = 1, 2, 4, 8
 
-_DT = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64}
+_DT = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64, "i16": torch.int16}
 
 
 def _chk(t, dt, n=None, name="tensor", optional=False):
@@ -255,6 +255,41 @@ def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, 
     _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
     _call("unreal_gemm_f32", int(transA), int(transB), M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias),
           ptr(mask), ldm, flags, splitk)
+
+
+class SplitWeights:
+    """bf16x3 shadow of one weight matrix as unreal_gemm_f32_split_nt wants its W operand: planes[t][n][k], rows padded
+    with zeros to a multiple of 32 k.  `refresh()` re-splits from the live fp32 weights (after an optimiser step)."""
+
+    def __init__(self, src, rows, cols, ld_src, transpose, offset=0):
+        self.src, self.rows, self.cols, self.ld_src, self.transpose, self.offset = src, rows, cols, ld_src, transpose, offset
+        self.N, self.K = (cols, rows) if transpose else (rows, cols)
+        self.ldw = (self.K + 31) // 32 * 32
+        self.plane = self.N * self.ldw
+        self.planes = torch.zeros(3 * self.plane, dtype=torch.int16, device=src.device)
+        self.refresh()
+
+    def refresh(self):
+        split_bf16x3(self.rows, self.cols, self.src[self.offset:], self.ld_src, self.transpose, self.planes, self.ldw,
+                     self.plane)
+
+
+def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane):
+    _chk(src, "f32", (rows - 1) * ld_src + cols, "src")
+    orows = cols if transpose else rows
+    _chk(dst, "i16", 2 * plane + orows * ld_dst, "dst")
+    _call("unreal_split_bf16x3", rows, cols, ptr(src), ld_src, int(bool(transpose)), ptr(dst), ld_dst, plane)
+
+
+def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0):
+    """C = A[M,K] @ W[N,K]^T (fp32-grade, 3 x bf16 split operands on the bf16 matrix cores); W is a SplitWeights."""
+    if W.N != N or W.K != K:
+        raise ValueError("split weights are [%d,%d], GEMM wants [%d,%d]" % (W.N, W.K, N, K))
+    _chk(A, "f32", (M - 1) * lda + K, "A"); _chk(C, "f32", (M - 1) * ldc + N, "C")
+    _chk(bias, "f32", N, "bias", optional=True)
+    _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
+    _call("unreal_gemm_f32_split_nt", M, N, K, ptr(A), lda, ptr(W.planes), W.ldw, W.plane, ptr(C), ldc, ptr(bias),
+          ptr(mask), ldm, flags)
 
 
 def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):

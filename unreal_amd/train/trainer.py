@@ -184,6 +184,7 @@ class Trainer(object):
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
         B, ws = self.B, self.base_ws
+        self.local_network.refresh_shadows()
         if self.use_lstm:
             ws.c0.copy_(self.lstm_c)
             ws.h0.copy_(self.lstm_h)
@@ -295,7 +296,7 @@ class Trainer(object):
         ops.gemm(1, 0, 256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592, flags=ops.GEMM_ATOMIC,
                  splitk=_splitk(256, 2592, rows))
         ops.colsum(rows, 2592, d_hp, 2592, g["b_pc_fc1"])
-        ops.gemm(0, 1, rows, 256, 2592, d_hp, 2592, p["W_pc_fc1"], 2592, gws.d_feat, 256)
+        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, net.shadow["pc_fc1_dgrad"], gws.d_feat, 256)
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
 
     def _train_vr(self):
@@ -335,6 +336,7 @@ class Trainer(object):
     def compute_gradients(self):
         """Rollout + the four loss branches; leaves the local mean gradient in local_network.grads.flat."""
         net = self.local_network
+        net.refresh_shadows()                  # bf16x3 weight planes follow the last optimiser step / load
         self._rollout()
         net.grads.flat.zero_()
         self.losses.zero_()
