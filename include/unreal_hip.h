@@ -79,6 +79,15 @@ int unreal_pc_returns(int B, int L, const int* seq_idx, const int* seq_len, cons
 /* clip_reward != 0: the reward column is np.clip(r, -1, 1) (ExperienceFrame of train/experience_lab_ver.py:14,18) */
 int unreal_lar_fill(int rows, int A, const int* last_action, const float* last_reward, const int* idx, float* xcat,
                     int ld, int col0, int clip_reward, void* stream);
+/* objective vectors of multimodal environments (environment/indoor_environment.py:70-73,113; train/experience.py:42-44;
+ * model/model.py:144,343): one [obj] fp32 row per ring slot next to the frame.  put: staged[b] -> the current slot
+ * of every active actor.  fill: xcat[row][col0..col0+obj) = objective of frame idx[row] shifted by slot_offset slots
+ * inside its actor's ring (-1 for the bootstrap value of train/trainer.py:300, which is fed the objective of the
+ * previous frame's state). */
+int unreal_objective_put(int B, int H1, int obj, const int* count, const int* active, const float* staged,
+                         float* r_objective, void* stream);
+int unreal_objective_fill(int rows, int obj, int H1, const float* r_objective, const int* idx, int slot_offset,
+                          float* xcat, int ld, int col0, void* stream);
 int unreal_gather_i32(int rows, const int* src, const int* idx, int* out, void* stream);
 int unreal_rollout_advance(int B, const int* terminal_t, int* active, int* active_log_t, int* n_steps,
                            int* terminal_end, void* stream);

@@ -30,10 +30,10 @@ class Frame(object):
         self.last_reward = last_reward
 
     def get_last_action_reward(self, action_size):
-        return concat_action_and_reward(self.last_action, action_size, self.last_reward)
+        return concat_action_and_reward(self.last_action, action_size, self.last_reward, self.state.get('objective'))
 
-    def get_action_reward(self, action_size):
-        return concat_action_and_reward(self.action, action_size, self.reward)
+    def get_action_reward(self, action_size):          # NB the objective of THIS frame's state (experience.py:27-32)
+        return concat_action_and_reward(self.action, action_size, self.reward, self.state.get('objective'))
 
 
 def clip_frame(frame):

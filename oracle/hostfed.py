@@ -41,3 +41,45 @@ class OracleLabEnv(object):
 
     def stop(self):
         pass
+
+
+class OracleIndoorEnv(object):
+    """Follows /root/reference/environment/indoor_environment.py:63-139 (MINOS wrapper) around a per-actor simulator
+    with reset() -> (obs uint8, measurements) and step(action) -> (obs | None, raw_reward, terminal, measurements):
+    state = {'image': obs/255, 'objective': measurements}; reward = raw_reward / termination_time (:111, the fork's
+    "reward clipping"); on a terminal step the state (image AND objective) is the previous one (:123-124); pixel change
+    from the two images (:128).  MINOS is absent from the image: tests drive this with
+    unreal_amd.environment.synthetic_sim.SyntheticIndoorSim -- parity unpinned by the reference for this path."""
+    ACTION_SIZE = 3                                   # indoor_environment.py:16-24
+
+    def __init__(self, sim, termination_time=50.0):
+        self.sim = sim
+        self.termination_time = termination_time
+        self.action_size = self.ACTION_SIZE
+        self.reset()
+
+    @staticmethod
+    def _preprocess_frame(image):
+        return image.astype(np.float32) / 255.0
+
+    def reset(self):
+        obs, meas = self.sim.reset()
+        self.last_state = {'image': self._preprocess_frame(obs), 'objective': np.asarray(meas, np.float64)}
+        self.last_action = 0
+        self.last_reward = 0
+
+    def process(self, action, flag=1):
+        obs, raw_reward, terminal, meas = self.sim.step(int(action))
+        reward = raw_reward / self.termination_time
+        if not terminal:
+            state = {'image': self._preprocess_frame(obs), 'objective': np.asarray(meas, np.float64)}
+        else:
+            state = self.last_state
+        pc = calc_pixel_change(state['image'], self.last_state['image'])
+        self.last_state = state
+        self.last_action = int(action)
+        self.last_reward = reward
+        return state, reward, terminal, pc
+
+    def stop(self):
+        pass

@@ -107,7 +107,7 @@ class OracleActor(object):
     def fill_step(self, p):                          # trainer.py:176-205
         env = self.env
         prev_state, last_action, last_reward = env.last_state, env.last_action, env.last_reward
-        lar = concat_action_and_reward(last_action, self.A, last_reward)
+        lar = concat_action_and_reward(last_action, self.A, last_reward, prev_state.get('objective'))
         pi, _ = self.run_base_policy_and_value(p, prev_state, lar)
         action = self.draws.choose_action(pi)
         _, reward, terminal, pc = env.process(action)
@@ -129,7 +129,7 @@ class OracleActor(object):
         score = None
         for _ in range(cfg["n_step_TD"]):
             last_action, last_reward = env.last_action, env.last_reward
-            lar = concat_action_and_reward(last_action, self.A, last_reward)
+            lar = concat_action_and_reward(last_action, self.A, last_reward, env.last_state.get('objective'))
             pi, v = self.run_base_policy_and_value(p, env.last_state, lar)
             action = self.draws.choose_action(pi)
             states.append(env.last_state)
@@ -266,7 +266,7 @@ class OracleTrainer(object):
         kw = dict(use_lstm=cfg["use_lstm"], use_pixel_change=cfg.get("use_pixel_change", False),
                   use_value_replay=cfg.get("use_value_replay", False),
                   use_reward_prediction=cfg.get("use_reward_prediction", False))
-        self.params = params if params is not None else M.init_params(cfg["action_size"], 0, seed=seed,
+        self.params = params if params is not None else M.init_params(cfg["action_size"], cfg.get("objective_size", 0), seed=seed,
                                                                       dtype=dtype, **kw)
         if draws is None:
             shared = RefDraws(np.random.RandomState(0xA3C))

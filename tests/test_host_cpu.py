@@ -119,3 +119,54 @@ def test_learning_rate_schedule_and_draw_streams():
     sa = {a._next() for _ in range(1000)}
     sb = {b._next() for _ in range(1000)}
     assert not (sa & sb) and len(sa) == 1000
+
+
+def test_oracle_indoor_contract_and_objective_concat():
+    """indoor_environment.py:63-139 contract of the oracle wrapper + experience.py:35-46 with an objective vector."""
+    from oracle.experience import concat_action_and_reward, Frame
+    from oracle.hostfed import OracleIndoorEnv
+    from unreal_amd.environment.synthetic_sim import SyntheticIndoorSim, SyntheticBatchIndoorSimulator
+    v = concat_action_and_reward(2, 3, -0.25, np.array([0.5, -1.0]))
+    np.testing.assert_array_equal(v, [0, 0, 1, -0.25, 0.5, -1.0])
+    kw = dict(episode_len=4, reward_p=0.3, big_reward_p=0.1, objective_size=2, termination_time=50.0)
+    env = OracleIndoorEnv(SyntheticIndoorSim(7, **kw), 50.0)
+    s0 = env.last_state
+    assert s0['image'].dtype == np.float32 and s0['image'].max() <= 1.0 and s0['objective'].shape == (2,)
+    f = Frame(s0, 0.5, 1, False, None, 0, 0)
+    np.testing.assert_array_equal(f.get_last_action_reward(3)[4:], s0['objective'])
+    np.testing.assert_array_equal(f.get_action_reward(3), np.concatenate(([0, 1, 0, 0.5], s0['objective'])))
+    seen = []
+    for t in range(4):
+        prev = env.last_state
+        state, r, term, pc = env.process(t % 3)
+        seen.append(r)
+        assert abs(r) <= 0.5 and (r * 8.0) == round(r * 8.0)          # raw / termination_time, exact in fp32
+        if term:
+            assert t == 3 and state is prev and float(pc.max()) == 0.0   # :123-124: previous state, objective included
+        else:
+            assert state is not prev and pc.shape == (20, 20)
+    # the batched simulator is B independent actors (same streams), objectives included
+    batch = SyntheticBatchIndoorSimulator(2, seed=5, **kw)
+    singles = [SyntheticIndoorSim(5 * 100003 + b, **kw) for b in range(2)]
+    fr, ob = batch.reset()
+    for b, s_ in enumerate(singles):
+        o, m = s_.reset()
+        np.testing.assert_array_equal(fr[b], o); np.testing.assert_array_equal(ob[b], m)
+    for t in range(6):
+        fr, rw, tm, ob = batch.step(np.array([t % 3, (t + 1) % 3]))
+        for b, s_ in enumerate(singles):
+            o, r, term, m = s_.step([t % 3, (t + 1) % 3][b])
+            if term:
+                o, m = s_.reset()
+            np.testing.assert_array_equal(fr[b], o); np.testing.assert_array_equal(ob[b], m)
+            assert rw[b] == np.float32(r) and tm[b] == int(term)
+
+
+def test_environment_objective_size_registry():
+    from unreal_amd.environment.environment import Environment
+    assert Environment.get_objective_size('maze', '') == 0 and Environment.get_objective_size('indoor', 'nope') == 0
+    Environment.register_indoor_config('rooms_test', 7)
+    assert Environment.get_objective_size('indoor', 'rooms_test') == 7
+    from unreal_amd.model.model import param_spec, xcat_ld
+    spec = dict((n, s) for n, s, _ in param_spec(3, 7))
+    assert spec["lstm_kernel"] == (256 + 3 + 1 + 7 + 256, 1024) and xcat_ld(3, 7) == 272 and xcat_ld(4, 0) == 264

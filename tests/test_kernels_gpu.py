@@ -661,3 +661,38 @@ def test_philox(ops):
     ops.philox_uniform(0, 0, a[:1])
     want = ((0x6627e8d5 >> 5) * 67108864.0 + (0xe169c58d >> 6)) / 9007199254740992.0
     assert float(a.cpu()[0]) == want
+
+
+def test_objective_put_and_fill():
+    """Objective vectors ride with the frames (indoor_environment.py:70-73,113; experience.py:42-44): put writes the
+    staged vector to each active actor's current slot, fill gathers it (optionally from a neighbouring slot of the same
+    actor's ring, wrapping) into the LSTM-input columns."""
+    from unreal_amd import ops
+    B, H, OBJ, LD, COL0 = 5, 6, 3, 272, 261
+    H1 = H + 1
+    ring = ops.Ring(B, H, DEV, objective_size=OBJ)
+    rs = np.random.RandomState(3)
+    want = np.zeros((B, H1, OBJ), np.float32)
+    counts = np.array([0, 3, 6, 7, 20], np.int32)
+    ring.count.copy_(torch.from_numpy(counts))
+    staged = rs.uniform(-1, 1, size=(B, OBJ)).astype(np.float32)
+    active = np.array([1, 0, 1, 1, 1], np.int32)
+    ops.objective_put(ring, torch.from_numpy(staged.reshape(-1)).to(DEV), torch.from_numpy(active).to(DEV))
+    for b in range(B):
+        if active[b]:
+            want[b, counts[b] % H1] = staged[b]
+    np.testing.assert_array_equal(ring.r_objective.cpu().numpy().reshape(B, H1, OBJ), want)
+    full = rs.uniform(-1, 1, size=(B, H1, OBJ)).astype(np.float32)
+    ring.r_objective.copy_(torch.from_numpy(full.reshape(-1)))
+    slots = np.array([0, 6, 3, 0, 5], np.int32)
+    idx = (np.arange(B) * H1 + slots).astype(np.int32)
+    for off in (0, -1, 1, -8):
+        x = torch.full((B * LD,), 9.0, device=DEV)
+        ops.objective_fill(ring, B, torch.from_numpy(idx).to(DEV), x, LD, COL0, slot_offset=off)
+        got = x.cpu().numpy().reshape(B, LD)
+        for b in range(B):
+            np.testing.assert_array_equal(got[b, COL0:COL0 + OBJ], full[b, (slots[b] + off) % H1])
+        got[:, COL0:COL0 + OBJ] = 9.0
+        assert (got == 9.0).all()
+    with pytest.raises(ValueError):
+        ops.objective_put(ops.Ring(2, 3, DEV), torch.zeros(2, device=DEV))

@@ -41,21 +41,21 @@ def _cfg(use_lstm, aux, H, T):
                 initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
 
 
-def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=1.0):
+def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=1.0, env_name=""):
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
     from unreal_amd.train.rmsprop_applier import RMSPropApplier
     from unreal_amd.train.trainer import Trainer, PhiloxDraws
     Environment.action_size = -1
-    A = Environment.get_action_size(env_type, "")
+    A = Environment.get_action_size(env_type, env_name)
     assert A == cfg["action_size"]
-    net = UnrealModel(A, 0, -1, cfg["use_lstm"], cfg["use_pixel_change"], cfg["use_value_replay"],
+    net = UnrealModel(A, Environment.get_objective_size(env_type, env_name), -1, cfg["use_lstm"], cfg["use_pixel_change"], cfg["use_value_replay"],
                       cfg["use_reward_prediction"], cfg["pixel_change_lambda"], cfg["entropy_beta"], DEV, seed=seed,
                       frame_scale=frame_scale)
     applier = RMSPropApplier(None, decay=cfg["rmsp_alpha"], momentum=0.0, epsilon=cfg["rmsp_epsilon"],
                              clip_norm=cfg["grad_norm_clip"], device=DEV)
     draws = RecordingDraws(PhiloxDraws(0xA3C, 0))
-    tr = Trainer(0, net, 7.0711e-4, None, applier, env_type, "", cfg["use_lstm"], cfg["use_pixel_change"],
+    tr = Trainer(0, net, 7.0711e-4, None, applier, env_type, env_name, cfg["use_lstm"], cfg["use_pixel_change"],
                  cfg["use_value_replay"], cfg["use_reward_prediction"], cfg["pixel_change_lambda"],
                  cfg["entropy_beta"], cfg["local_t_max"], cfg["n_step_TD"], cfg["gamma"], cfg["gamma_pc"],
                  cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws,
@@ -238,23 +238,10 @@ def test_maze_environment_reference_surface():
     env.stop()
 
 
-def test_hostfed_lab_contract_matches_oracle():
-    """SURVEY 8f-1 / BASELINE config 4: host simulators (synthetic stand-in for DeepMind Lab: uint8 frames, A = 6,
-    sparse rewards incl. values > 1, fixed-length episodes) -> pinned staging -> HBM ring -> the same batched
-    learner, against the oracle running the Lab wrapper contract (lab_environment.py:78-119) with the upstream
-    replay semantics (experience_lab_ver.py) actor by actor.  Parity unpinned by the reference (no Lab fixtures)."""
-    from oracle.hostfed import OracleLabEnv
-    from unreal_amd.environment.synthetic_sim import SyntheticBatchSimulator, SyntheticActorSim
-    B, H, T = 3, 40, 20
-    cfg = _cfg(True, True, H, T)
-    cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
-    kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
-    sim = SyntheticBatchSimulator(B, seed=4, **kw)
-    net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0)
-    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
-    edraws = [ExplicitDraws() for _ in range(B)]
-    envs = [OracleLabEnv(SyntheticActorSim(4 * 100003 + b, **kw), 6) for b in range(B)]
-    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params, envs=envs)
+def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_frame, iters=3):
+    """Fill the replay on both sides with the recorded draws, compare the ring, then `iters` updates: per-actor actions /
+    rewards / step counts, mean losses, mean gradient of every variable, global norm."""
+    from unreal_amd import ops
     while not tr._full:
         assert tr.process(None, 0) == (0, None)
     assert len(draws.log) == H
@@ -263,14 +250,12 @@ def test_hostfed_lab_contract_matches_oracle():
             edraws[b].action_u.append(float(step_u[b]))
     orc.fill()
     np.testing.assert_array_equal(tr.ring.count.cpu().numpy(), [a.exp.count for a in orc.actors])
-    # ring contents after the fill: frames, clipped rewards, terminals, pixel change
-    from unreal_amd import ops
+    # ring contents after the fill: frames, rewards, terminals, pixel change (+ whatever check_frame adds)
     H1 = H + 1
     fr = tr.ring.frames.cpu().numpy().reshape(B, H1, 84, 84, 3)
     rr = tr.ring.r_reward.cpu().numpy().reshape(B, H1)
     rt = tr.ring.r_terminal.cpu().numpy().reshape(B, H1)
     rpc = tr.ring.r_pc.cpu().numpy().reshape(B, H1, 20, 20)
-    saw_clip = False
     for b in range(B):
         x = orc.actors[b].exp
         for i in range(x.top, x.count):
@@ -279,9 +264,10 @@ def test_hostfed_lab_contract_matches_oracle():
             assert rr[b, i % H1] == f.reward and bool(rt[b, i % H1]) == bool(f.terminal)
             # reference: float32 arithmetic on obs/255; kernel: exact integer SAD / (48*255) -> 1e-6 relative
             np.testing.assert_allclose(rpc[b, i % H1], f.pixel_change, rtol=2e-6, atol=1e-7)
-        saw_clip |= any(abs(orc.actors[b].env.last_reward) > 1 for _ in [0])
+            if check_frame is not None:
+                check_frame(b, i % H1, f)
     global_t = 0
-    for it in range(3):
+    for it in range(iters):
         draws.log.clear()
         lr = tr._anneal_learning_rate(global_t)
         tr.compute_gradients()
@@ -318,4 +304,63 @@ def test_hostfed_lab_contract_matches_oracle():
             assert np.abs(g_dev[name] - gr).max() <= tol, (it, name, np.abs(g_dev[name] - gr).max(), np.abs(gr).max())
         assert abs(norm_dev - norm_o) <= 2e-4 * max(1.0, norm_o)
         global_t += steps_dev
-    assert any(abs(r) > 1 for a in orc.actors for r in [f.last_reward for f in a.exp.frames.values()]) is False
+
+
+def test_hostfed_lab_contract_matches_oracle():
+    """SURVEY 8f-1 / BASELINE config 4: host simulators (synthetic stand-in for DeepMind Lab: uint8 frames, A = 6,
+    sparse rewards incl. values > 1, fixed-length episodes) -> pinned staging -> HBM ring -> the same batched
+    learner, against the oracle running the Lab wrapper contract (lab_environment.py:78-119) with the upstream
+    replay semantics (experience_lab_ver.py) actor by actor.  Parity unpinned by the reference (no Lab fixtures)."""
+    from oracle.hostfed import OracleLabEnv
+    from unreal_amd.environment.synthetic_sim import SyntheticBatchSimulator, SyntheticActorSim
+    B, H, T = 3, 40, 20
+    cfg = _cfg(True, True, H, T)
+    cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
+    kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
+    sim = SyntheticBatchSimulator(B, seed=4, **kw)
+    net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0)
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+    edraws = [ExplicitDraws() for _ in range(B)]
+    envs = [OracleLabEnv(SyntheticActorSim(4 * 100003 + b, **kw), 6) for b in range(B)]
+    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params, envs=envs)
+    _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, None)
+    # the simulator did emit rewards above 1 and the replay holds them clipped (experience_lab_ver.py:14,18)
+    assert all(abs(f.last_reward) <= 1 and abs(f.reward) <= 1 for a in orc.actors for f in a.exp.frames.values())
+    assert float(tr.ring.r_reward.abs().max()) <= 1.0
+
+
+def test_hostfed_indoor_objective_matches_oracle():
+    """SURVEY 8f-4 / BASELINE config 5: the multimodal MINOS contract (indoor_environment.py:63-139): A = 3, every
+    observation carries a measurement vector ('objective') that is stored beside the frame and concatenated into the
+    LSTM input (experience.py:42-44, model.py:144,343; the bootstrap value gets the PREVIOUS state's objective,
+    trainer.py:300); rewards are divided by termination_time and not clipped; this fork's replay buckets.  Synthetic
+    simulator (MINOS is not in the image): parity unpinned by the reference, checked against the oracle."""
+    from oracle.hostfed import OracleIndoorEnv
+    from unreal_amd.environment.environment import Environment
+    from unreal_amd.environment.synthetic_sim import SyntheticBatchIndoorSimulator, SyntheticIndoorSim
+    B, H, T, OBJ = 3, 40, 20, 5
+    cfg = _cfg(True, True, H, T)
+    cfg.update(action_size=3, objective_size=OBJ, initial_learning_rate=7.0711e-4)
+    kw = dict(episode_len=23, reward_p=0.15, big_reward_p=0.05, objective_size=OBJ, termination_time=50.0)
+    Environment.register_indoor_config("synthetic_rooms", OBJ)
+    sim = SyntheticBatchIndoorSimulator(B, seed=5, **kw)
+    net, applier, tr, draws = _build(cfg, B, seed=11, env_type="indoor", env_name="synthetic_rooms", simulator=sim,
+                                     frame_scale=1.0 / 255.0)
+    assert net.K_x == 256 + 3 + 1 + OBJ and net.params.shaped("lstm_kernel").shape == (net.K_x + 256, 1024)
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+    edraws = [ExplicitDraws() for _ in range(B)]
+    envs = [OracleIndoorEnv(SyntheticIndoorSim(5 * 100003 + b, **kw), 50.0) for b in range(B)]
+    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params, envs=envs)
+    robj = [None]
+
+    def check_objective(b, slot, f):
+        if robj[0] is None:
+            robj[0] = tr.ring.r_objective.cpu().numpy().reshape(B, H + 1, OBJ)
+        np.testing.assert_array_equal(robj[0][b, slot], f.state['objective'].astype(np.float32))
+
+    _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_objective)
+    rews = [f.reward for a in orc.actors for f in a.exp.frames.values()]
+    assert min(rews) < 0 < max(rews) and max(abs(r) for r in rews) <= 0.5       # scaled by 1/termination_time
+    # the objective rows of the LSTM kernel received gradient
+    g = net.grads.shaped("lstm_kernel")[256 + 4:256 + 4 + OBJ]
+    assert float(g.abs().max()) > 0

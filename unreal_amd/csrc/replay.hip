@@ -146,6 +146,29 @@ __global__ void lar_fill_kernel(int rows, int A, const int* last_action, const f
   xcat[(size_t)r * ld + col0 + k] = v;
 }
 
+// objective vectors ride with the frames, one [obj] row per ring slot (indoor_environment.py:70-73,113: the
+// 'objective' entry of a state).  put: the staged objective of every active actor goes to its CURRENT slot.
+__global__ void objective_put_kernel(int B, int H1, int obj, const int* count, const int* active, const float* staged,
+                                     float* r_objective) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * obj) return;
+  int b = g / obj, j = g - b * obj;
+  if (active && !active[b]) return;
+  r_objective[((size_t)b * H1 + count[b] % H1) * obj + j] = staged[g];
+}
+
+// xcat[row][col0 .. col0+obj) = objective of frame idx[row], or of the slot `slot_offset` before/after it in the same
+// actor's ring (trainer.py:300: the bootstrap value is fed the objective of the PREVIOUS frame's state)
+__global__ void objective_fill_kernel(int rows, int obj, int H1, const float* r_objective, const int* idx, int slot_offset,
+                                      float* xcat, int ld, int col0) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= rows * obj) return;
+  int r = g / obj, j = g - r * obj;
+  int f = idx[r], b = f / H1, s = f - b * H1;
+  s = (s + slot_offset % H1 + H1) % H1;
+  xcat[(size_t)r * ld + col0 + j] = r_objective[((size_t)b * H1 + s) * obj + j];
+}
+
 // gather a per-frame int attribute of the ring into a dense [rows] array
 __global__ void gather_i32_kernel(int rows, const int* src, const int* idx, int* out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,6 +289,21 @@ int unreal_lar_fill(int rows, int A, const int* last_action, const float* last_r
   if (rows <= 0 || A <= 0 || ld < col0 + A + 1) return UNREAL_EINVAL;
   hipLaunchKernelGGL(lar_fill_kernel, GRID1(rows * (ld - col0)), rows, A, last_action, last_reward, idx, xcat, ld,
                      col0, clip_reward);
+  return unreal_launch_status();
+}
+
+int unreal_objective_put(int B, int H1, int obj, const int* count, const int* active, const float* staged,
+                         float* r_objective, void* stream) {
+  if (B <= 0 || H1 < 2 || obj <= 0 || !count || !staged || !r_objective) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(objective_put_kernel, GRID1(B * obj), B, H1, obj, count, active, staged, r_objective);
+  return unreal_launch_status();
+}
+
+int unreal_objective_fill(int rows, int obj, int H1, const float* r_objective, const int* idx, int slot_offset,
+                          float* xcat, int ld, int col0, void* stream) {
+  if (rows <= 0 || obj <= 0 || H1 < 2 || !r_objective || !idx || !xcat || ld < col0 + obj) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(objective_fill_kernel, GRID1(rows * obj), rows, obj, H1, r_objective, idx, slot_offset, xcat, ld,
+                     col0);
   return unreal_launch_status();
 }
 

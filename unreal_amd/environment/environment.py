@@ -1,12 +1,18 @@
 """Environment factory with the reference's surface (/root/reference/environment/environment.py:11-102).
 
-Only the maze is a device environment this round; lab / indoor / gym need simulators that are not in
-the image and raise."""
+Only the maze is a device environment; lab / indoor actors are HOST-FED (hostfed_environment.py) by simulator objects
+the caller supplies, because deepmind_lab / minos / gym are not in the image."""
 
 
 class Environment(object):
     action_size = -1          # class-cached: first query wins (environment.py:13,46-47)
     LOG_DIR = None
+    # stands in for minos.config.sim_config (indoor_environment.py:27-29): env_name -> {'objective_size': n}
+    INDOOR_CONFIG = {}
+
+    @staticmethod
+    def register_indoor_config(env_name, objective_size):
+        Environment.INDOOR_CONFIG[env_name] = {'objective_size': int(objective_size)}
 
     @staticmethod
     def create_environment(env_type, env_name, termination_time=50.0, env_args=None, thread_index=0):
@@ -32,6 +38,8 @@ class Environment(object):
 
     @staticmethod
     def get_objective_size(env_type, env_name):
+        if env_type == 'indoor':               # environment.py:68-72 -> indoor_environment.py:26-29
+            return Environment.INDOOR_CONFIG.get(env_name, {}).get('objective_size', 0)
         return 0
 
     def __init__(self):

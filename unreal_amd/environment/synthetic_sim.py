@@ -56,3 +56,61 @@ class SyntheticBatchSimulator(object):
             rewards[b], terminals[b] = r, int(t)
             frames[b] = a.reset() if t else obs          # the trainer's env.reset() after a terminal
         return frames, rewards, terminals
+
+
+class SyntheticIndoorSim(SyntheticActorSim):
+    """Stand-in for a MINOS RoomSimulator actor (indoor_environment.py:63-139): also returns a measurement vector
+    ('objective') with every observation, and raw rewards that the wrapper divides by termination_time.  Raw rewards are
+    multiples of termination_time / 8 so the scaled reward is exact in fp32."""
+
+    def __init__(self, seed, objective_size=5, termination_time=50.0, **kw):
+        SyntheticActorSim.__init__(self, seed, **kw)
+        self.objective_size, self.termination_time = objective_size, termination_time
+
+    def _meas(self):
+        return self.rs.uniform(-1.0, 1.0, size=self.objective_size).astype(np.float32)
+
+    def reset(self):
+        return SyntheticActorSim.reset(self), self._meas()
+
+    def step(self, action):
+        """-> (obs uint8 or None when terminal, raw reward, terminal, measurements)"""
+        self.t += 1
+        u = self.rs.random_sample()
+        unit = self.termination_time / 8.0
+        reward = 4.0 * unit if u < self.big_reward_p else (unit if u < self.reward_p else (-unit if u < 3 * self.reward_p else 0.0))
+        terminal = self.t >= self.episode_len
+        obs = None if terminal else self._obs()
+        return obs, reward, terminal, self._meas()
+
+
+class SyntheticBatchIndoorSimulator(object):
+    """B independent SyntheticIndoorSim actors behind the batched host-fed interface (with objectives)."""
+
+    def __init__(self, batch, seed=5, objective_size=5, **kw):
+        self.actors = [SyntheticIndoorSim(seed * 100003 + b, objective_size=objective_size, **kw) for b in range(batch)]
+        self.B, self.objective_size = batch, objective_size
+        self._obj = np.zeros((batch, objective_size), np.float32)
+
+    def reset(self, mask=None):
+        out = np.zeros((self.B, 84, 84, 3), np.uint8)
+        for b, a in enumerate(self.actors):
+            if mask is None or mask[b]:
+                out[b], self._obj[b] = a.reset()
+        return out, self._obj.copy()
+
+    def step(self, actions, active=None):
+        """-> frames, rewards (raw), terminals, objectives; where terminal: the post-reset observation and objective."""
+        frames = np.zeros((self.B, 84, 84, 3), np.uint8)
+        rewards = np.zeros(self.B, np.float32)
+        terminals = np.zeros(self.B, np.int32)
+        for b, a in enumerate(self.actors):
+            if active is not None and not active[b]:
+                continue
+            obs, r, t, meas = a.step(int(actions[b]))
+            rewards[b], terminals[b] = r, int(t)
+            if t:
+                frames[b], self._obj[b] = a.reset()       # the trainer's env.reset() after a terminal
+            else:
+                frames[b], self._obj[b] = obs, meas
+        return frames, rewards, terminals, self._obj.copy()

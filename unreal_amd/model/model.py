@@ -20,7 +20,22 @@ import torch
 from .. import ops
 
 ALIGN = 64
-XLD = 264          # row stride of the [fc(256) | last_action_reward | pad] LSTM input buffer
+XLD = 264          # row stride of the [fc(256) | last_action_reward | pad] LSTM input buffer (no objective vector)
+
+
+def xcat_ld(action_size, objective_size=0):
+    """Row stride of the [fc(256) | one-hot last action | last reward | objective | pad] buffer (multiple of 8)."""
+    return max(XLD, (256 + action_size + 1 + objective_size + 7) // 8 * 8)
+
+
+def _small_chunks(n):
+    """n columns as widths the small-N backward kernel is instantiated for."""
+    out = []
+    while n > 0:
+        w = n if n in (1, 3, 4, 5, 6, 7) else (1 if n == 2 else (7 if n >= 10 else n - 3 if n - 3 in (3, 4, 5, 6) else 4))
+        out.append(w)
+        n -= w
+    return out
 
 
 def param_spec(action_size, objective_size=0, use_lstm=True, use_pixel_change=True,
@@ -71,13 +86,13 @@ class FlatParams(object):
 class PathWS(object):
     """Activations of one trunk pass over `rows` frames (time-major rows t*B + b)."""
 
-    def __init__(self, rows, B, device, save_c1=True, lstm=True):
+    def __init__(self, rows, B, device, save_c1=True, lstm=True, xld=XLD):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
-        self.rows, self.B = rows, B
+        self.rows, self.B, self.xld = rows, B, xld
         self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
         self.c1 = f(rows * ops.C1_DIM) if save_c1 else None
         self.f2 = f(rows * ops.F2_DIM)
-        self.xcat = torch.zeros(rows * XLD, dtype=torch.float32, device=device)
+        self.xcat = torch.zeros(rows * xld, dtype=torch.float32, device=device)
         if lstm:
             self.gates = f(rows * 1024)
             self.c = f(rows * 256)
@@ -117,8 +132,8 @@ class UnrealModel(object):
                  use_value_replay, use_reward_prediction, pixel_change_lambda, entropy_beta, device,
                  segnet_param_dict=None, image_shape=(84, 84), is_training=True, n_classes=0,
                  segnet_lambda=1.0, dropout=0.0, for_display=False, frame_scale=1.0, seed=0):
-        if objective_size != 0:
-            raise NotImplementedError("objective vectors (indoor_environment) are outside this round's scope")
+        if objective_size < 0:
+            raise ValueError("objective_size must be >= 0")
         if segnet_param_dict is not None and segnet_param_dict.get("segnet_mode", 0) not in (0, None):
             raise NotImplementedError("only the vanilla encoder (segnet_mode == 0) is on the hot path")
         if tuple(image_shape) != (84, 84):
@@ -128,6 +143,8 @@ class UnrealModel(object):
         self._objective_size = objective_size
         self._thread_index = thread_index
         self._use_lstm = use_lstm
+        self.K_x = 256 + action_size + 1 + objective_size      # LSTM input width (model.py:343)
+        self.xld = xcat_ld(action_size, objective_size)
         self._use_pixel_change = use_pixel_change
         self._use_value_replay = use_value_replay
         self._use_reward_prediction = use_reward_prediction
@@ -156,7 +173,7 @@ class UnrealModel(object):
         Evaluate.process / batch-1 runner, i.e. after any optimiser step, load or restore."""
         if self._shadow is None:
             p, A = self.p, self._action_size
-            K_x = 256 + A + 1
+            K_x = self.K_x
             S = ops.SplitWeights
             sh = dict(fc1_fwd=S(p["W_base_fc1"], 2592, 256, 256, True),
                       fc1_dgrad=S(p["W_base_fc1"], 2592, 256, 256, False))
@@ -223,27 +240,31 @@ class UnrealModel(object):
         self.base_lstm_state_out = (z, z.clone())     # (c, h) like LSTMStateTuple
 
     # -- batched building blocks -----------------------------------------------------------------------
-    def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False):
-        """conv encoder -> fc (+ last_action_reward columns and the input half of the LSTM gates) for rows
-        [row0, row0+nrows) of a path workspace."""
+    def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
+                    objective_slot_offset=0):
+        """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
+        rows [row0, row0+nrows) of a path workspace.  `objective_slot_offset` = -1 reproduces trainer.py:300, where the
+        bootstrap value is fed the objective of the previous frame's state."""
         p = self.p
         idx = ws.frame_idx[row0:row0 + nrows]
         f2 = ws.f2[row0 * ops.F2_DIM:]
-        xcat = ws.xcat[row0 * XLD:]
+        xcat = ws.xcat[row0 * self.xld:]
         c1 = ws.c1[row0 * ops.C1_DIM:] if (save_c1 and ws.c1 is not None) else None
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
                         p["W_base_conv2"], p["b_base_conv2"], f2, c1)
         sh = self.shadow
-        ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, XLD, bias=p["b_base_fc1"],
+        ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
                           flags=ops.GEMM_RELU)
         if not self._use_lstm:
             return
         A = self._action_size
         if lar_from_ring:
-            ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, XLD)
+            ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, self.xld)
         else:
-            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, XLD, clip=clip_lar)
-        ops.gemm_split_nt(nrows, 1024, 256 + A + 1, xcat, XLD, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
+            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, self.xld, clip=clip_lar)
+        if self._objective_size:
+            ops.objective_fill(ring, nrows, idx, xcat, self.xld, 256 + A + 1, slot_offset=objective_slot_offset)
+        ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
 
     def lstm_step(self, ws, t, B):
         """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math)."""
@@ -258,11 +279,12 @@ class UnrealModel(object):
         """(tensor, ld) of the features the heads read: LSTM outputs, or the fc output in FF mode."""
         if self._use_lstm:
             return ws.h[row0 * 256:], 256
-        return ws.xcat[row0 * XLD:], XLD
+        return ws.xcat[row0 * self.xld:], self.xld
 
-    def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False):
+    def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False,
+                      objective_slot_offset=0):
         """conv encoder -> fc -> (LSTM over T steps from ws.c0/ws.h0); rows = T*B listed in ws.frame_idx."""
-        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar)
+        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar, objective_slot_offset)
         if self._use_lstm:
             for t in range(T):
                 self.lstm_step(ws, t, B)
@@ -274,7 +296,7 @@ class UnrealModel(object):
         rows = T * B
         if self._use_lstm:
             A = self._action_size
-            K_x = 256 + A + 1
+            K_x = self.K_x
             W = p["lstm_kernel"]
             Wh = W[K_x * 1024:]
             gws.dc.zero_()
@@ -288,10 +310,13 @@ class UnrealModel(object):
             dW = g["lstm_kernel"]
             # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
             # last_action_reward rows by the small-N outer-product kernel (no padded third tile)
-            ops.gemm(1, 0, 256, 1024, rows, ws.xcat, XLD, gws.d_gates, 1024, dW, 1024,
+            ops.gemm(1, 0, 256, 1024, rows, ws.xcat, self.xld, gws.d_gates, 1024, dW, 1024,
                      flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, rows))
-            ops.linear_small_bwd(rows, 1024, A + 1, gws.d_gates, 1024, ws.xcat[256:], XLD, None, None, 0, False,
-                                 dW[256 * 1024:], None, dw_stride_k=1, dw_stride_n=1024)
+            c0 = 256
+            for w in _small_chunks(K_x - 256):         # last action, last reward (and objective) rows
+                ops.linear_small_bwd(rows, 1024, w, gws.d_gates, 1024, ws.xcat[c0:], self.xld, None, None, 0, False,
+                                     dW[c0 * 1024:], None, dw_stride_k=1, dw_stride_n=1024)
+                c0 += w
             if T > 1:
                 r1 = (T - 1) * B
                 ops.gemm(1, 0, 256, 1024, r1, ws.h, 256, gws.d_gates[B * 1024:], 1024, dW[K_x * 1024:], 1024,
@@ -301,10 +326,10 @@ class UnrealModel(object):
                          flags=ops.GEMM_ATOMIC, splitk=_splitk(256, 1024, B))
             ops.colsum(rows, 1024, gws.d_gates, 1024, g["lstm_bias"])
             ops.gemm_split_nt(rows, 256, 1024, gws.d_gates, 1024, sh["lstm_fc_dgrad"], gws.d_fc, 256, mask=ws.xcat,
-                              ldm=XLD, flags=ops.GEMM_RELU_MASK)
+                              ldm=self.xld, flags=ops.GEMM_RELU_MASK)
             d_fc = gws.d_fc
         else:
-            ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, XLD)
+            ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, self.xld)
             d_fc = d_feat
         ops.gemm(1, 0, 2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256, flags=ops.GEMM_ATOMIC,
                  splitk=_splitk(2592, 256, rows))
@@ -332,7 +357,7 @@ class UnrealModel(object):
     def _b1_ws(self):
         if self._b1 is None:
             dev = self._device
-            self._b1 = dict(ring=ops.Ring(3, 1, dev), ws=PathWS(3, 3, dev, save_c1=False, lstm=self._use_lstm),
+            self._b1 = dict(ring=ops.Ring(3, 1, dev, objective_size=self._objective_size), ws=PathWS(3, 3, dev, save_c1=False, lstm=self._use_lstm, xld=self.xld),
                             pi=torch.zeros(self._action_size, device=dev), v=torch.zeros(1, device=dev),
                             hp=torch.zeros(2592, device=dev), q=torch.zeros(400, device=dev),
                             z=torch.zeros(3, device=dev))
@@ -352,6 +377,8 @@ class UnrealModel(object):
             lar = np.asarray(last_action_reward, dtype=np.float32)
             ring.r_last_action[0] = int(np.argmax(lar[:self._action_size]))
             ring.r_last_reward[0] = float(lar[self._action_size])
+            if self._objective_size:                   # [one-hot action | reward | objective] (experience.py:42-44)
+                ring.r_objective[:self._objective_size].copy_(torch.from_numpy(lar[self._action_size + 1:]))
         return ring, ws
 
     def _run_trunk1(self, s_t, last_action_reward, state):

@@ -66,8 +66,9 @@ def kernel_timer_stop():
 class Ring(object):
     """Device replay ring + per-actor environment state (layout: include/unreal_hip.h)."""
 
-    def __init__(self, B, H, device):
+    def __init__(self, B, H, device, objective_size=0):
         self.B, self.H, self.H1 = B, H, H + 1
+        self.objective_size = objective_size
         n = B * self.H1
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
         self.frames = torch.empty(n * FRAME_BYTES, dtype=torch.uint8, device=device)
@@ -77,6 +78,7 @@ class Ring(object):
         self.r_last_action = z(n, dt=torch.int32)
         self.r_last_reward = z(n)
         self.r_pc = torch.empty(n * PC_CELLS, dtype=torch.float32, device=device)
+        self.r_objective = z(n * objective_size) if objective_size else None
         self.pos = z(B * 2, dt=torch.int32)
         self.last_action = z(B, dt=torch.int32)
         self.last_reward = z(B)
@@ -194,6 +196,23 @@ def lar_fill(rows, A, last_action, last_reward, idx, xcat, ld, col0=256, clip=Fa
     if idx is None and (last_action.numel() < rows or last_reward.numel() < rows):
         raise ValueError("lar_fill: per-row sources too short")
     _call("unreal_lar_fill", rows, A, ptr(last_action), ptr(last_reward), ptr(idx), ptr(xcat), ld, col0, int(clip))
+
+
+def objective_put(ring, staged, active=None):
+    """staged [B][obj] -> the current slot of every (active) actor."""
+    obj = ring.objective_size
+    if not obj:
+        raise ValueError("this ring stores no objective vectors")
+    _chk(staged, "f32", ring.B * obj, "staged objective"); _chk(active, "i32", ring.B, "active", optional=True)
+    _call("unreal_objective_put", ring.B, ring.H1, obj, ptr(ring.count), ptr(active), ptr(staged), ptr(ring.r_objective))
+
+
+def objective_fill(ring, rows, idx, xcat, ld, col0, slot_offset=0):
+    obj = ring.objective_size
+    if not obj:
+        raise ValueError("this ring stores no objective vectors")
+    _chk(idx, "i32", rows, "idx"); _chk(xcat, "f32", (rows - 1) * ld + col0 + obj, "xcat")
+    _call("unreal_objective_fill", rows, obj, ring.H1, ptr(ring.r_objective), ptr(idx), slot_offset, ptr(xcat), ld, col0)
 
 
 def gather_i32(src, idx, out):

@@ -71,7 +71,7 @@ class Trainer(object):
         self.simulator = simulator
         # upstream replay semantics for host-fed (Lab-contract) actors: zero / non-zero reward buckets and reward
         # clipping (train/experience_lab_ver.py:14,18,76-80); this fork's buckets for the maze (train/experience.py)
-        self.rp_mode = 0 if env_type == "maze" else 1
+        self.rp_mode = 1 if env_type == "lab" else 0      # indoor: this fork's train/experience.py, like the maze
         self.thread_index = thread_index
         self.learning_rate_input = learning_rate_input
         self.env_type, self.env_name = env_type, env_name
@@ -116,16 +116,23 @@ class Trainer(object):
             self.environment = BatchedMazeEnvironment(B, self.experience_history_size, dev)
         else:
             from ..environment.hostfed_environment import HostFedEnvironment
+            indoor = self.env_type == "indoor"
+            if indoor and getattr(self.simulator, "objective_size", 0) != self.objective_size:
+                raise ValueError("simulator.objective_size != Environment.get_objective_size(%r, %r) = %d"
+                                 % (self.env_type, self.env_name, self.objective_size))
             self.environment = HostFedEnvironment(self.simulator, B, self.experience_history_size, dev,
-                                                  action_size=A, clip_reward=True)
+                                                  action_size=A, clip_reward=not indoor,
+                                                  objective_size=self.objective_size,
+                                                  reward_divisor=termination_time if indoor else 1.0)
         self.ring = self.environment.ring
         self.experience = Experience(self.experience_history_size, ring=self.ring)
         lstm = self.use_lstm
         aux = self.use_pixel_change or self.use_value_replay
-        self.base_ws = PathWS(T * B, B, dev, save_c1=True, lstm=lstm)
-        self.boot_ws = PathWS(B, B, dev, save_c1=False, lstm=lstm)
-        self.aux_ws = PathWS(Ta * B, B, dev, save_c1=True, lstm=lstm) if aux else None
-        self.rp_ws = PathWS(3 * B, B, dev, save_c1=True, lstm=False) if self.use_reward_prediction else None
+        xld = self.local_network.xld
+        self.base_ws = PathWS(T * B, B, dev, save_c1=True, lstm=lstm, xld=xld)
+        self.boot_ws = PathWS(B, B, dev, save_c1=False, lstm=lstm, xld=xld)
+        self.aux_ws = PathWS(Ta * B, B, dev, save_c1=True, lstm=lstm, xld=xld) if aux else None
+        self.rp_ws = PathWS(3 * B, B, dev, save_c1=True, lstm=False, xld=xld) if self.use_reward_prediction else None
         rows = max(T, Ta if aux else 0, 3 if self.use_reward_prediction else 0) * B
         self.gws = GradWS(rows, B, dev, lstm=lstm, pc=self.use_pixel_change, A=A)
         f = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
@@ -227,7 +234,8 @@ class Trainer(object):
             bw.h0.copy_(self.lstm_h)
         self.ring.cur_idx(out=bw.frame_idx[:B])
         feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=False, save_c1=False,
-                                     clip_lar=self.rp_mode == 1)   # frame.get_action_reward(): stored (clipped) reward
+                                     clip_lar=self.rp_mode == 1,   # frame.get_action_reward(): stored (clipped) reward
+                                     objective_slot_offset=-1)     # ... and the objective of frame.state (:300)
         net.value_forward(B, feat, ld, self.boot_v)
         if self.use_lstm:                      # episode ended -> reset_state() (trainer.py:293)
             ops.reset_state(B, self.terminal_end, self.lstm_c, self.lstm_h)
