@@ -84,6 +84,15 @@ def main():
                    timeit(lambda: ops.gemm_split_nt(M, N, K, A_, lda, Bt_, C_, N)), flop=2.0 * M * N * K)
             del A_, Bt_, C_
 
+    if not FILT or FILT in "split gemm tn":
+        for name, M, N, K in (("dW_fc1", 2592, 256, R), ("dW_lstm_x", 256, 1024, R), ("dW_lstm_h", 256, 1024, R - B),
+                              ("dW_pc_fc1", 256, 2592, R)):
+            A_ = rnd(K * M); B_ = rnd(K * N); C_ = torch.zeros(M * N, device=DEV)
+            sk = _splitk(M, N, K)
+            report("split_tn %s M=%d N=%d K=%d sk=%d" % (name, M, N, K, sk),
+                   timeit(lambda: ops.gemm_split_tn(M, N, K, A_, M, B_, N, C_, N, splitk=sk)), flop=2.0 * M * N * K)
+            del A_, B_, C_
+
     if not FILT or FILT in "encoder":
         for N in (R, B):
             pool = torch.randint(0, 2, (N * ops.FRAME_BYTES,), dtype=torch.uint8, device=DEV)

@@ -108,19 +108,25 @@ __device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p) 
   *reinterpret_cast<u32x4*>(S + (t * ROWS + r) * ROW_B + c * 16) = v;
 }
 
-template <int BM, int BN>
+// SWZ: the 16-byte k chunk c of row r sits at chunk c ^ ((r >> 4) & 3) (transposing stores of the TN kernel)
+template <int BM, int BN, bool SWZ = false>
 __device__ __forceinline__ void read_frags(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int li, int kh,
                                            int ks, bf16x8 (&af)[BM / 64][3], bf16x8 (&bf)[BN / 64][3]) {
+  const int c = 2 * ks + kh;
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-      af[i][t] = *reinterpret_cast<const bf16x8*>(As + (t * BM + wm * (BM / 2) + i * 32 + li) * ROW_B + (16 * ks + 8 * kh) * 2);
+    for (int t = 0; t < 3; ++t) {
+      const int r = wm * (BM / 2) + i * 32 + li;
+      af[i][t] = *reinterpret_cast<const bf16x8*>(As + (t * BM + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
+    }
 #pragma unroll
   for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
-      bf[j][t] = *reinterpret_cast<const bf16x8*>(Bs + (t * BN + wn * (BN / 2) + j * 32 + li) * ROW_B + (16 * ks + 8 * kh) * 2);
+    for (int t = 0; t < 3; ++t) {
+      const int r = wn * (BN / 2) + j * 32 + li;
+      bf[j][t] = *reinterpret_cast<const bf16x8*>(Bs + (t * BN + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
+    }
 }
 
 template <int TM, int TN>
@@ -270,6 +276,133 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad:  C[M,N] += A[K,M]^T * B[K,N]   (both operands activations, k = the row index; split-K with fp32 atomics)
+//
+// Same MFMA core; the difference is the staging.  A thread owns a 4(k) x 4(m) patch of the 32(k) x 128(m) tile: four
+// 16-byte loads (one per k row, 512 B contiguous per row across 32 lanes), a register transpose, and per m a split of
+// the 4 k values into 3 bf16 planes stored as 8 bytes at [plane][m][k] -- the same LDS image the NT kernel reads.
+// The stores of 32 lanes go to rows 4 apart (320 B = 16 banks), so the 16-byte chunk index is XOR-swizzled with row
+// bits 4-5: 2-way instead of 8-way bank conflicts; the fragment reads apply the same swizzle and stay conflict-free.
+struct SplitTnArgs {
+  int M, N, K;
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int ntx, nty, splitk, ktiles_per_split;
+};
+
+__device__ __forceinline__ void tn_piece_load(const float* __restrict__ P, int ld, int K, int c0, int k0, f32x4 (&reg)[4]) {
+  const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+  const int col = min(c0 + 4 * m4, ld - 4);                 // columns past the matrix: pulled inside, never stored
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = min(k0 + 4 * k4 + kk, K - 1);             // rows past K: re-read the last row, zeroed in the store
+    reg[kk] = *reinterpret_cast<const f32x4*>(P + (size_t)k * ld + col);
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&reg)[4], int klim) {
+  const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+  bool ok[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) ok[kk] = 4 * k4 + kk < klim;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 4 * m4 + j;
+    f32x2 x01 = {ok[0] ? reg[0][j] : 0.f, ok[1] ? reg[1][j] : 0.f}, x23 = {ok[2] ? reg[2][j] : 0.f, ok[3] ? reg[3][j] : 0.f};
+    u32x2 pl[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bf16x2 h01 = __builtin_convertvector(x01, bf16x2), h23 = __builtin_convertvector(x23, bf16x2);
+      pl[t] = (u32x2){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+      if (t < 2) {
+        x01 = x01 - __builtin_convertvector(h01, f32x2);
+        x23 = x23 - __builtin_convertvector(h23, f32x2);
+      }
+    }
+    const int off = (((k4 >> 1) ^ ((r >> 4) & 3)) * 2 + (k4 & 1)) * 8;       // swizzled 16-B chunk, 8-B half
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+      *reinterpret_cast<u32x2*>(S + (t * ROWS + r) * ROW_B + off) = pl[t];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + A_BYTES;
+
+  // XCD-aware order: one K slab per XCD at a time, its C tiles swept x-fastest, so the slab of B (re-read by every
+  // row of tiles) and the slab of A (re-read by every column) are served by that XCD's L2.
+  const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
+  const int tiles = p.ntx * p.nty;
+  const int slab = (s / tiles) * 8 + xcd, tile = s % tiles;
+  if (slab >= p.splitk) return;
+  const int bx = tile % p.ntx, by = tile / p.ntx;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt0 = slab * p.ktiles_per_split, kt1 = min(nk_total, kt0 + p.ktiles_per_split);
+  if (kt0 >= kt1) return;
+  const int nkt = kt1 - kt0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  tn_piece_load(p.A, p.lda, p.K, m0, kt0 * BK, ra);
+  tn_piece_load(p.B, p.ldb, p.K, n0, kt0 * BK, rb);
+  tn_piece_store<BM>(As, ra, p.K - kt0 * BK);
+  tn_piece_store<BN>(Bs, rb, p.K - kt0 * BK);
+  {
+    const int k1 = (kt0 + min(1, nkt - 1)) * BK;
+    tn_piece_load(p.A, p.lda, p.K, m0, k1, ra);
+    tn_piece_load(p.B, p.ldb, p.K, n0, k1, rb);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nkt; ++it) {
+    bf16x8 af[TM][3], bf[TN][3];
+    read_frags<BM, BN, true>(As, Bs, wm, wn, li, kh, 0, af, bf);
+    mma_frags<TM, TN>(af, bf, acc);
+    read_frags<BM, BN, true>(As, Bs, wm, wn, li, kh, 1, af, bf);
+    __syncthreads();                                   // every wave has read tile `it`
+    // unconditional like the NT kernel: one basic block, the compiler interleaves split VALU, loads and MFMAs
+    const int kcur = (kt0 + min(it + 1, nkt - 1)) * BK, knext = (kt0 + min(it + 2, nkt - 1)) * BK;
+    tn_piece_store<BM>(As, ra, p.K - kcur);
+    tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
+    tn_piece_store<BN>(Bs, rb, p.K - kcur);
+    tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
+    mma_frags<TM, TN>(af, bf, acc);
+    __syncthreads();                                   // tile `it + 1` is visible
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); 32 lanes = 128 B per atomic
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + li;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
 // weights -> bf16x3 planes: dst[t][r][c] = term_t(src[r][c]) (transpose = 0) or dst[t][c][r] (transpose = 1);
 // 32x32 tiles through LDS so both sides stay coalesced.  Padding columns of dst are left as the caller zeroed them.
 __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, const float* __restrict__ src, int ld_src,
@@ -325,6 +458,24 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
     if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
+  return unreal_launch_status();
+}
+
+int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                             int splitk, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return UNREAL_EINVAL;
+  if ((lda & 3) || (ldb & 3) || lda < 4 || ldb < 4 || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return UNREAL_EINVAL;
+  SplitTnArgs a;
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.ntx = (N + 127) / 128; a.nty = (M + 127) / 128;
+  const int nk = (K + BK - 1) / BK;
+  if (splitk < 1) splitk = 1;
+  if (splitk > nk) splitk = nk;
+  a.ktiles_per_split = (nk + splitk - 1) / splitk;
+  a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+  const long grid = (long)a.ntx * a.nty * ((a.splitk + 7) / 8 * 8);
+  if (grid > 0x7fffffffL) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(gemm_split_tn_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
 

@@ -311,6 +311,12 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
           ptr(mask), ldm, flags)
 
 
+def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1):
+    """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the bf16 matrix cores, split-K atomics into C)."""
+    _chk(A, "f32", (K - 1) * lda + M, "A"); _chk(B, "f32", (K - 1) * ldb + N, "B"); _chk(C, "f32", (M - 1) * ldc + N, "C")
+    _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, splitk)
+
+
 def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):
     _chk(pre, "f32", rows * 1024); _chk(bias, "f32", 1024); _chk(c_prev, "f32", rows * 256)
     _chk(gates_act, "f32", rows * 1024, optional=True); _chk(c_out, "f32", rows * 256)

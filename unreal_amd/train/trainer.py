@@ -301,8 +301,8 @@ class Trainer(object):
         ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
                           g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
         from ..model.model import _splitk
-        ops.gemm(1, 0, 256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592, flags=ops.GEMM_ATOMIC,
-                 splitk=_splitk(256, 2592, rows))
+        ops.gemm_split_tn(256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592,
+                              splitk=_splitk(256, 2592, rows))
         ops.colsum(rows, 2592, d_hp, 2592, g["b_pc_fc1"])
         ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, net.shadow["pc_fc1_dgrad"], gws.d_feat, 256)
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
