@@ -3,7 +3,7 @@
 import ctypes, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-so = "/tmp/libexp_enc.so"
+so = os.path.join(ROOT, "gpurun_out", "libexp_enc.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUNREAL_ABLATE",
                        os.path.join(ROOT, "unreal_amd/csrc/encoder.hip"), "-o", so])
 lib = ctypes.CDLL(so)
