@@ -176,57 +176,64 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[PA];
+  f32x4 ra[2][PA];      // A pieces travel TWO tiles ahead (HBM; set it&1 holds tile it+1), W pieces one (L2)
   u32x4 rw[PW];
   const int shift = (int)((unsigned)by * 7u % (unsigned)nkt);    // de-synchronise the panel sweeps of different rows
 #define KT_AT(i) (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift)
   {
     const int k0 = KT_AT(0) * BK;
 #pragma unroll
-    for (int q = 0; q < PA; ++q) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k0, q);
+    for (int q = 0; q < PA; ++q) ra[0][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k0, q);
 #pragma unroll
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[q], p.K - k0, q);
+    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[0][q], p.K - k0, q);
 #pragma unroll
     for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q);
-    const int k1 = KT_AT(min(1, nkt - 1)) * BK;
+    const int k1 = KT_AT(min(1, nkt - 1)) * BK, k2 = KT_AT(min(2, nkt - 1)) * BK;
 #pragma unroll
-    for (int q = 0; q < PA; ++q) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k1, q);
+    for (int q = 0; q < PA; ++q) ra[0][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k1, q);
+#pragma unroll
+    for (int q = 0; q < PA; ++q) ra[1][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k2, q);
 #pragma unroll
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q);
   }
   __syncthreads();
 
-  for (int it = 0; it < nkt; ++it) {
-    bf16x8 af[TM][3], bf[TN][3];
-    if (!(SPLIT_ABLATE & 4)) {
-      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 0, af, bf);
-      mma_frags<TM, TN>(af, bf, acc);
-      // second half: fragments are read before the barrier, the MFMAs run after it next to the split of the next tile
-      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 1, af, bf);
-    }
-    __syncthreads();                                   // every wave has read tile `it`
-    // Tile it+1 leaves the registers (split, LDS store) and tile it+2 is fetched into them, piece by piece, next to
-    // the second-half MFMAs: loads spread between MFMAs keep the CU's vector-memory queue short (8 waves issuing 10
-    // loads each at once stall at issue, and the in-order MFMAs behind them with it).  The fetch then has a whole
-    // iteration to land.  Everything here is unconditional -- the last passes re-store / re-fetch a valid tile that
-    // is never read -- so that the section stays ONE basic block and the compiler interleaves it (explicit
-    // sched_group_barrier pipelines measured 5-10 % slower than its own schedule).
-    const int kcur = KT_AT(min(it + 1, nkt - 1)) * BK, knext = KT_AT(min(it + 2, nkt - 1)) * BK;
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      if (!(SPLIT_ABLATE & 2) || it == 0) a_piece_store<BM>(As, ra[q], p.K - kcur, q);
-      if (!(SPLIT_ABLATE & 1)) ra[q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, knext, q);
-    }
-#pragma unroll
-    for (int q = 0; q < PW; ++q) {
-      if (!(SPLIT_ABLATE & 2) || it == 0) w_piece_store<BN>(Bs, rw[q], q);
-      if (!(SPLIT_ABLATE & 1)) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, knext, q);
-    }
-    if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);
-    __syncthreads();                                   // tile `it + 1` is visible
+  // One K tile.  Tile it+1 leaves register set S (split, LDS store) and tile it+3 is fetched into it, piece by piece,
+  // next to the second-half MFMAs: loads spread between MFMAs keep the CU's vector-memory queue short (8 waves
+  // issuing 10 loads each at once stall at issue, and the in-order MFMAs behind them with it).  An A fetch then has
+  // TWO iterations to land: with one, the streaming operand's HBM time added to the MFMA time instead of hiding under
+  // it (all resident blocks ask for their next tile in the same phase).  Everything is unconditional -- the last passes
+  // re-store / re-fetch a valid tile that is never read -- so the section stays ONE basic block and the compiler
+  // interleaves it (explicit sched_group_barrier pipelines measured 5-10 % slower than its own schedule).
+#define SPLIT_NT_TILE(S, IT)                                                                                        \
+  {                                                                                                                 \
+    bf16x8 af[TM][3], bf[TN][3];                                                                                    \
+    if (!(SPLIT_ABLATE & 4)) {                                                                                      \
+      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 0, af, bf);                                                        \
+      mma_frags<TM, TN>(af, bf, acc);                                                                               \
+      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 1, af, bf);   /* second half: read before, multiplied after */     \
+    }                                                                                                               \
+    __syncthreads();                                   /* every wave has read tile IT */                            \
+    const int kcur = KT_AT(min((IT) + 1, nkt - 1)) * BK, kw = KT_AT(min((IT) + 2, nkt - 1)) * BK,                   \
+              ka = KT_AT(min((IT) + 3, nkt - 1)) * BK;                                                              \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM>(As, ra[S][q], p.K - kcur, q);                         \
+      if (!(SPLIT_ABLATE & 1)) ra[S][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, ka, q);                   \
+    }                                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) w_piece_store<BN>(Bs, rw[q], q);                                        \
+      if (!(SPLIT_ABLATE & 1)) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, kw, q);                       \
+    }                                                                                                               \
+    if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);                                                        \
+    __syncthreads();                                   /* tile IT + 1 is visible */                                 \
   }
+  for (int it = 0; it < nkt; it += 2) {
+    SPLIT_NT_TILE(0, it)
+    if (it + 1 < nkt) SPLIT_NT_TILE(1, it + 1)
+  }
+#undef SPLIT_NT_TILE
 
   // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip)
   constexpr int CLD = BN + 4;
