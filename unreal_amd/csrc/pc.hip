@@ -6,8 +6,11 @@
 //
 // The transposed conv is evaluated per OUTPUT PARITY as a small dense GEMM (no scatter, no atomics):
 //   out[2a+pa][2b+pb][co] = sum_{da,db in {0,1}} sum_ci in[a-da][b-db][ci] * W[pa+2da][pb+2db][co][ci]
-// i.e. 4 GEMMs of M = 100 positions, K = 4*32, N = 1+A channels (padded to the 16-wide MFMA tile); wave w
-// of a frame-group owns parity w, so one weight fragment read feeds all of its position tiles.
+// Forward: the four parities read the SAME input rows, so they are packed side by side into the MFMA's N dimension:
+// ONE GEMM of M = 100 base positions (a,b), K = 4 taps x 32 channels, N = 4 parities x (1+A) channels = 20 of 32
+// columns (per-parity GEMMs would fill 5 of 16).  Operands are split into three bf16 terms when they are staged into
+// LDS (hp per frame, the weights once per workgroup) and multiplied as six term-pair v_mfma_f32_16x16x32_bf16, the
+// scheme and error level of csrc/gemm_split.hip.  Backward (below) still runs per parity on the fp32 MFMA.
 // Same group/LDS organisation and MFMA operand convention as encoder.hip: the next frame's inputs are
 // fetched into registers behind the current frame's math, outputs leave through LDS in 16 B/lane rows.
 #include "common.h"
@@ -59,72 +62,152 @@ __device__ __forceinline__ void hp_store(float* hp, int gtid, const f32x4 (&r)[H
   }
 }
 
-// deconv of NT position tiles of output parity `par`; pre-activations (+bias) of the CO real channels -> dec
-template <int NT>
-__device__ __forceinline__ void deconv_tiles(const float* hp, const float* wd, float* dec, int par, int mt0, int i, int q,
-                                             int CO, float bias) {
-  f32x4 acc[NT];
-  int a[NT], b[NT];
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2p __attribute__((ext_vector_type(2)));
+
+constexpr int HPP_ROW = 80;                        // bytes per hp row in a bf16 plane: 32 ci + 16 B pad
+constexpr int HPP_PLANE = HP_ROWS * HPP_ROW;       // 6720
+constexpr int WDP_ROW = 80;                        // bytes per (tap, column) weight row: 32 ci + pad
+constexpr int WDP_PLANE = 4 * 32 * WDP_ROW;        // [dd(4)][n(32)] rows = 10240
+constexpr int FWD_GRP_BYTES = 3 * HPP_PLANE + PC_CELLS * DEC_LD_F * 4 + PC_CELLS * 8 * 4;   // hp planes | dec | dout
+
+__device__ __forceinline__ void split4p(const f32x4& v, u32x2p (&pl)[3]) {
+  f32x2p x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int m = min((mt0 + t) * 16 + i, 99);
+  for (int t = 0; t < 3; ++t) {
+    const bf16x2p h01 = __builtin_convertvector(x01, bf16x2p), h23 = __builtin_convertvector(x23, bf16x2p);
+    pl[t] = (u32x2p){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    if (t < 2) {
+      x01 = x01 - __builtin_convertvector(h01, f32x2p);
+      x23 = x23 - __builtin_convertvector(h23, f32x2p);
+    }
+  }
+}
+
+// hp [81][32] fp32 (registers) -> three bf16 planes in LDS
+__device__ __forceinline__ void hp_store_planes(unsigned char* hpp, int gtid, const f32x4 (&r)[HP_V]) {
+#pragma unroll
+  for (int c = 0; c < HP_V; ++c) {
+    const int id = gtid + 256 * c;
+    if (id < C2_POS * 8) {
+      u32x2p pl[3];
+      split4p(r[c], pl);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2p*>(hpp + t * HPP_PLANE + (id >> 3) * HPP_ROW + (id & 7) * 8) = pl[t];
+    }
+  }
+}
+
+#define PC_SPLIT_MMA(A, B, C)                                          \
+  do {                                                                 \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[0], C, 0, 0, 0); \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[2], C, 0, 0, 0); \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[1], C, 0, 0, 0); \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[0], C, 0, 0, 0); \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[1], C, 0, 0, 0); \
+    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[0], C, 0, 0, 0); \
+  } while (0)
+
+// deconv of the wave's position tiles (tile ids mt0 and mt0 + 4 when < 7) for ALL parities and channels:
+// column n = par * CO + co (n < 4 * CO <= 32, two 16-wide column tiles); pre-activations + bias -> dec
+template <bool TWO_NT>
+__device__ __forceinline__ void deconv_packed(const unsigned char* hpp, const unsigned char* wdp, float* dec, int mt0, int i,
+                                              int q, int CO, const float (&bias)[2]) {
+  constexpr int NTL = TWO_NT ? 2 : 1;
+  const int ntiles = (mt0 + 4 < 7) ? 2 : 1;              // wave-uniform
+  f32x4 acc[2][NTL];
+  int a[2], b[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int m = min((mt0 + 4 * t) * 16 + i, 99);
     a[t] = m / 10;
     b[t] = m % 10;
   }
 #pragma unroll
   for (int dd = 0; dd < 4; ++dd) {
     const int da = dd >> 1, db = dd & 1;
-    int row[NT];
+    bf16x8 bw[NTL][3];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int y = a[t] - da, x = b[t] - db;
-      row[t] = ((y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS) * HP_LD + 4 * q;
-    }
+    for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-    for (int cch = 0; cch < 2; ++cch) {
-      f32x4 av[NT];
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(wd + ((((par * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
+      for (int pl = 0; pl < 3; ++pl)
+        bw[nt][pl] = *reinterpret_cast<const bf16x8*>(wdp + pl * WDP_PLANE + ((dd * 32 + nt * 16 + i)) * WDP_ROW + 16 * q);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const f32x4*>(hp + row[t] + 16 * cch);
+    for (int t = 0; t < 2; ++t) {
+      if (t < ntiles) {
+        const int y = a[t] - da, x = b[t] - db;
+        const int row = (y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS;
+        bf16x8 av[3];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int pl = 0; pl < 3; ++pl)
+          av[pl] = *reinterpret_cast<const bf16x8*>(hpp + pl * HPP_PLANE + row * HPP_ROW + 16 * q);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = MFMA16(av[t][s], bw[s], acc[t]);
+        for (int nt = 0; nt < NTL; ++nt) PC_SPLIT_MMA(av, bw[nt], acc[t][nt]);
+      }
     }
   }
-  if (i < CO) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int n = nt * 16 + i;
+    if (n < 4 * CO) {
+      const int par = n / CO, co = n - par * CO;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (mt0 + t) * 16 + 4 * q + r;
-        if (m < 100)
-          dec[((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * DEC_LD_F + i] = acc[t][r] + bias;
-      }
+      for (int t = 0; t < 2; ++t)
+        if (t < ntiles) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = (mt0 + 4 * t) * 16 + 4 * q + r;
+            if (m < 100)
+              dec[((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * DEC_LD_F + co] = acc[t][nt][r] + bias[nt];
+          }
+        }
+    }
   }
 }
 
 __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
-  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_F * 4 + PC_CELLS * 8 * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + WD_ELEMS * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FWD_GRP_BYTES + 3 * WDP_PLANE];
   const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  float* hp = reinterpret_cast<float*>(smem + grp * GRP_BYTES);
-  float* dec = hp + HP_ROWS * HP_LD;
+  unsigned char* hpp = smem + grp * FWD_GRP_BYTES;
+  float* dec = reinterpret_cast<float*>(hpp + 3 * HPP_PLANE);
   float* dout = dec + PC_CELLS * DEC_LD_F;      // staged d_dec of the frame: [400][CO] dense
-  float* wd = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
+  unsigned char* wdp = smem + 2 * FWD_GRP_BYTES;
   const int A = p.A, CO = 1 + p.A;
 
-  // weights -> [par][dd][cch][q][co(16)][s], ci = 16cch + 4q + s
-  for (int e = threadIdx.x; e < WD_ELEMS; e += 512) {
-    int s = e & 3, co = (e >> 2) & 15, qq = (e >> 6) & 3, cch = (e >> 8) & 1, dd = (e >> 9) & 3, par = e >> 11;
-    int ky = (par >> 1) + 2 * (dd >> 1), kx = (par & 1) + 2 * (dd & 1);
-    wd[e] = deconv_w(p, ky, kx, co, 16 * cch + 4 * qq + s);
+  // weights -> bf16x3 planes [plane][dd][n = par*CO + co (32, zero padded)][ci(32)]: tap dd of parity par is
+  // W[pa + 2da][pb + 2db][co][ci]
+  for (int e = threadIdx.x; e < 4 * 32 * 8; e += 512) {      // one f32x4 of ci per item
+    const int c4 = e & 7, n = (e >> 3) & 31, dd = e >> 8;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < 4 * CO) {
+      const int par = n / CO, co = n - par * CO;
+      const int ky = (par >> 1) + 2 * (dd >> 1), kx = (par & 1) + 2 * (dd & 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = deconv_w(p, ky, kx, co, 4 * c4 + k);
+    }
+    u32x2p pl[3];
+    split4p(v, pl);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2p*>(wdp + t * WDP_PLANE + (dd * 32 + n) * WDP_ROW + c4 * 8) = pl[t];
   }
-  for (int e = gtid; e < 3 * HP_LD; e += 256) hp[C2_POS * HP_LD + e] = 0.f;
-  const float bias = (i == 0) ? p.bv[0] : ((i <= A) ? p.ba[i - 1] : 0.f);
+  for (int e = gtid; e < 3 * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the three hp planes
+    const int t = e / (3 * HPP_ROW / 4), w = e % (3 * HPP_ROW / 4);
+    reinterpret_cast<uint32_t*>(hpp + t * HPP_PLANE + C2_POS * HPP_ROW)[w] = 0u;
+  }
+  float bias[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = nt * 16 + i;
+    const int co = n % CO;
+    bias[nt] = (n < 4 * CO) ? (co == 0 ? p.bv[0] : p.ba[co - 1]) : 0.f;
+  }
+  const bool two_nt = 4 * CO > 16;
   float loss_acc = 0.f;
 
   const int stride = gridDim.x * 2;
@@ -133,7 +216,7 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
     const int n0 = blockIdx.x * 2 + grp;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre);
-      hp_store(hp, gtid, pre);
+      hp_store_planes(hpp, gtid, pre);
     }
   }
   int prev = -1;
@@ -142,22 +225,33 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
     const bool valid = n < p.N;
     const int nn = n + stride;
     const bool has_next = nn < p.N;
-    __syncthreads();  // [S0] hp of frame n staged; dout of the previous frame complete
+    __syncthreads();  // [S0] hp planes of frame n staged; dout of the previous frame complete
     if (prev >= 0 && p.d_dec) {
       f32x4* dst = reinterpret_cast<f32x4*>(p.d_dec + (size_t)prev * PC_CELLS * CO);
       for (int id = gtid; id < PC_CELLS * CO / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dout)[id];
     }
     if (has_next) hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre);
+    // this frame's targets / action / mask: fetched now so that their latency sits behind the deconv
+    float tg[2] = {0.f, 0.f};
+    int act = 0;
+    bool on = true;
+    if (valid && p.d_dec) {
+      tg[0] = p.target[(size_t)n * PC_CELLS + gtid];
+      tg[1] = p.target[(size_t)n * PC_CELLS + min(gtid + 256, PC_CELLS - 1)];
+      act = p.action[n];
+      on = p.mask[n] != 0;
+    }
     if (valid) {
-      deconv_tiles<4>(hp, wd, dec, gw, 0, i, q, CO, bias);
-      deconv_tiles<3>(hp, wd, dec, gw, 4, i, q, CO, bias);
+      if (two_nt) deconv_packed<true>(hpp, wdp, dec, gw, i, q, CO, bias);
+      else deconv_packed<false>(hpp, wdp, dec, gw, i, q, CO, bias);
     }
     __syncthreads();  // [S1] dec complete; hp free; dout drained
     if (valid) {
       // dueling combine per output position (pre-activations in dec)
-      const int act = p.action ? p.action[n] : 0;
-      const bool on = p.mask ? (p.mask[n] != 0) : true;
-      for (int pos = gtid; pos < PC_CELLS; pos += 256) {
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi) {
+        const int pos = gtid + 256 * pi;
+        if (pos >= PC_CELLS) break;
         const float* d = dec + pos * DEC_LD_F;
         const float vpre = d[0];
         const float V = fmaxf(vpre, 0.f);
@@ -171,7 +265,7 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
         }
         if (p.d_dec) {
           const float qa = V + adv[act] - mean;
-          const float diff = p.target[(size_t)n * PC_CELLS + pos] - qa;
+          const float diff = tg[pi] - qa;
           const float dq = on ? -p.lambda * diff * p.grad_scale : 0.f;
           if (on) loss_acc += 0.5f * p.lambda * diff * diff;
           float* o = dout + pos * CO;
@@ -181,7 +275,7 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
         }
       }
     }
-    if (has_next) hp_store(hp, gtid, pre);
+    if (has_next) hp_store_planes(hpp, gtid, pre);
     prev = valid ? n : -1;
   }
   __syncthreads();
