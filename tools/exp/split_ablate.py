@@ -12,19 +12,19 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out", "ablate")
 os.makedirs(OUT, exist_ok=True)
-SHAPES = (("fc_fwd", 81920, 256, 2592), ("pc_fc1", 81920, 2592, 256), ("d_fc", 81920, 256, 1024))
+SHAPES = (("fc_fwd", 81920, 256, 2592), ("pc_fc1", 81920, 2592, 256), ("d_fc", 81920, 256, 1024), ("fc_roll", 4096, 256, 2592), ("dh_rec", 4096, 256, 1024))
 
 
 def build(bits):
     so = os.path.join(OUT, "split_%d.so" % bits)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DSPLIT_ABLATE=%d" % bits, os.path.join(ROOT, "unreal_amd/csrc/gemm_split.hip"), "-o", so]
-                          + sys.argv[1:])
+                           "-DSPLIT_ABLATE=%d" % bits,
+                           os.path.join(ROOT, "unreal_amd/csrc/gemm_split.hip"), "-o", so] + sys.argv[1:])
     return ctypes.CDLL(so)
 
 
 def main():
-    for bits in (0, 16, 8, 1, 3):
+    for bits in (0, 8, 1, 3, 4):
         lib = build(bits)
         f = lib.unreal_gemm_f32_split_nt
         f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_long,

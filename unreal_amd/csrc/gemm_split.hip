@@ -146,7 +146,9 @@ __device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x
     }
 }
 
-template <int BM, int BN, bool VEC>
+// DEEP: activation tiles travel two K tiles ahead instead of one.  Measured on one device, same process: +20 % on the
+// 64x64 kernel's long-K shapes (4096 x 256 x 2592: 76 -> 62 us), -3 % on the 128x128 kernel (16 more live registers).
+template <int BM, int BN, bool VEC, bool DEEP = (BM == 64)>
 __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int PA = BM * BK / 1024, PW = 3 * BN / 64;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[2][PA];      // A pieces travel TWO tiles ahead (HBM; set it&1 holds tile it+1), W pieces one (L2)
+  f32x4 ra[2][PA];      // DEEP: A pieces travel TWO tiles ahead (set it&1 holds tile it+1); W pieces always one (L2)
   u32x4 rw[PW];
   const int shift = (int)((unsigned)by * 7u % (unsigned)nkt);    // de-synchronise the panel sweeps of different rows
 #define KT_AT(i) (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift)
@@ -193,8 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
     const int k1 = KT_AT(min(1, nkt - 1)) * BK, k2 = KT_AT(min(2, nkt - 1)) * BK;
 #pragma unroll
     for (int q = 0; q < PA; ++q) ra[0][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k1, q);
+    if (DEEP) {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) ra[1][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k2, q);
+      for (int q = 0; q < PA; ++q) ra[1][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k2, q);
+    }
 #pragma unroll
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q);
   }
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
     }                                                                                                               \
     __syncthreads();                                   /* every wave has read tile IT */                            \
     const int kcur = KT_AT(min((IT) + 1, nkt - 1)) * BK, kw = KT_AT(min((IT) + 2, nkt - 1)) * BK,                   \
-              ka = KT_AT(min((IT) + 3, nkt - 1)) * BK;                                                              \
+              ka = KT_AT(min((IT) + (DEEP ? 3 : 2), nkt - 1)) * BK;                                                 \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
       if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM>(As, ra[S][q], p.K - kcur, q);                         \
       if (!(SPLIT_ABLATE & 1)) ra[S][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, ka, q);                   \
@@ -229,9 +233,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
     if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);                                                        \
     __syncthreads();                                   /* tile IT + 1 is visible */                                 \
   }
-  for (int it = 0; it < nkt; it += 2) {
-    SPLIT_NT_TILE(0, it)
-    if (it + 1 < nkt) SPLIT_NT_TILE(1, it + 1)
+  if (DEEP) {
+    for (int it = 0; it < nkt; it += 2) {
+      SPLIT_NT_TILE(0, it)
+      if (it + 1 < nkt) SPLIT_NT_TILE(1, it + 1)
+    }
+  } else {
+    for (int it = 0; it < nkt; ++it) SPLIT_NT_TILE(0, it)
   }
 #undef SPLIT_NT_TILE
 
