@@ -128,8 +128,17 @@ int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const
 /* bf16x3 shadow of a weight matrix src[rows][cols]: dst[t][r][c] (transpose = 0) or dst[t][c][r] (transpose = 1),
  * t = 0..2 the bf16 terms (sum of the three == src to 2^-24 relative).  dst padding is left untouched (zero it once).
  * Refreshed after every RMSProp step / checkpoint restore. */
-int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, uint16_t* dst, int ld_dst,
-                        long plane_stride, void* stream);
+int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
+                        int ld_dst, long plane_stride, void* stream);
+/* row_perm = 1 (1024 output rows only): LSTM gate interleave, output row of column n = g*256 + u of the kernel is
+ * (u/16)*64 + g*16 + u%16, the layout unreal_lstm_step_fwd multiplies by. */
+/* One BasicLSTMCell step (model/model.py:110,346-351; gates i,j,f,o, forget_bias 1): the recurrent half
+ * h_prev[rows,256] * Wh is multiplied on the split-operand path and the gate math runs in the GEMM epilogue.
+ * gates [rows][1024]: in = input-half pre-activations (x * Wx), out = activated gates (saved for the backward);
+ * Wh3 = gate-interleaved bf16x3 shadow of the kernel's recurrent rows (transpose = 1, row_perm = 1). */
+int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint16_t* Wh3, int ldw, long plane_stride,
+                         float* gates, const float* bias, const float* c_prev, float* c_out, float* h_out, int ld_h,
+                         void* stream);
 int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
                           float* c_out, float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,

@@ -82,3 +82,38 @@ def test_split_tn_wgrad_matches_fp64(M, N, K, sk):
     if K > 1:
         with pytest.raises(RuntimeError):                 # misaligned operand: refused (-22), nothing launched
             ops.gemm_split_tn(M, N, K - 1, dev(A).view(-1)[1:], lda, dev(B), ldb, C, ldc)
+
+
+@pytest.mark.parametrize("rows", [4096, 70, 3])
+def test_fused_lstm_step_matches_unfused_and_fp64(rows):
+    """unreal_lstm_step_fwd == split GEMM (accumulate) + unreal_lstm_gates_fwd bit for bit (same association of the
+    sums), and both match a float64 BasicLSTMCell step (gates i,j,f,o, forget_bias 1)."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(rows)
+    Wh = rs.uniform(-0.07, 0.07, size=(256, 1024)); bias = rs.uniform(-0.1, 0.1, size=1024)
+    h_prev = rs.uniform(-1, 1, size=(rows, 256)); c_prev = rs.uniform(-2, 2, size=(rows, 256))
+    pre_x = rs.uniform(-2, 2, size=(rows, 1024))
+    Whd = dev(Wh).view(-1)
+    sh_nat = ops.SplitWeights(Whd, 256, 1024, 1024, True)
+    sh_il = ops.SplitWeights(Whd, 256, 1024, 1024, True, row_perm=1)
+    # reference path
+    g0 = dev(pre_x).view(-1); c0 = torch.zeros(rows * 256, device=DEV); h0 = torch.zeros(rows * 256, device=DEV)
+    ops.gemm_split_nt(rows, 1024, 256, dev(h_prev).view(-1), 256, sh_nat, g0, 1024, flags=ops.GEMM_ACCUM)
+    ops.lstm_gates_fwd(rows, g0, dev(bias), dev(c_prev).view(-1), g0, c0, h0)
+    # fused
+    g1 = dev(pre_x).view(-1); c1 = torch.zeros(rows * 256, device=DEV); h1 = torch.full((rows * 264,), 3.0, device=DEV)
+    ops.lstm_step_fwd(rows, dev(h_prev).view(-1), sh_il, g1, dev(bias), dev(c_prev).view(-1), c1, h1, ld_h=264)
+    assert torch.equal(g0, g1) and torch.equal(c0, c1)
+    h1m = h1.view(rows, 264)
+    assert torch.equal(h0.view(rows, 256), h1m[:, :256]) and float(h1m[:, 256:].min()) == 3.0
+    # float64
+    pre = pre_x + h_prev.astype(np.float32).astype(np.float64) @ Wh.astype(np.float32).astype(np.float64) + bias
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    i, j, f, o = sig(pre[:, :256]), np.tanh(pre[:, 256:512]), sig(pre[:, 512:768] + 1.0), sig(pre[:, 768:])
+    c = c_prev * f + i * j
+    h = np.tanh(c) * o
+    np.testing.assert_allclose(c1.cpu().numpy().reshape(rows, 256), c, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(h1m[:, :256].cpu().numpy(), h, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(g1.cpu().numpy().reshape(rows, 1024), np.concatenate([i, j, f, o], 1), atol=2e-5, rtol=2e-5)
+    with pytest.raises(ValueError):
+        ops.lstm_step_fwd(rows, dev(h_prev).view(-1), sh_nat, g1, dev(bias), dev(c_prev).view(-1), c1, h1)

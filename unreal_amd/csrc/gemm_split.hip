@@ -48,6 +48,8 @@ struct SplitArgs {
   int flags;
   int vecA;
   int nbx, nby;
+  // fused LSTM step (EPI == 1): C is the gate buffer [M][1024] (in: input-half pre-activations, out: activated gates)
+  const float* c_prev; float* c_out; float* h_out; int ld_h;
 };
 
 // One 16-byte piece of the A tile per call (piece p of ROWS*BK/1024).  Branch-free on purpose: rows past the end
@@ -148,7 +150,7 @@ __device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x
 
 // DEEP: activation tiles travel two K tiles ahead instead of one.  Measured on one device, same process: +20 % on the
 // 64x64 kernel's long-K shapes (4096 x 256 x 2592: 76 -> 62 us), -3 % on the 128x128 kernel (16 more live registers).
-template <int BM, int BN, bool VEC, bool DEEP = (BM == 64)>
+template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int PA = BM * BK / 1024, PW = 3 * BN / 64;
@@ -254,6 +256,28 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
       for (int r = 0; r < 16; ++r)
         Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
   __syncthreads();
+  if (EPI == 1) {
+    // BasicLSTMCell gate math fused into the recurrent GEMM (model/model.py:110, TF BasicLSTMCell: gates i,j,f,o,
+    // forget_bias 1).  The weight shadow is gate-interleaved (unreal_split_bf16x3 row_perm = 1): this block's 64
+    // columns are hidden units u0..u0+15 of the four gates, so the tile holds everything one unit needs.
+    const int u0 = bx * (BN / 4);
+    for (int id = threadIdx.x; id < BM * (BN / 4); id += 256) {
+      const int r = id / (BN / 4), ul = id % (BN / 4);
+      const int row = m0 + r, u = u0 + ul;
+      if (row >= p.M) continue;
+      float* pre = p.C + (size_t)row * p.ldc;
+      const float* cs = Cs + r * CLD + ul;
+      const float gi = 1.f / (1.f + expf(-((cs[0] + pre[u]) + p.bias[u])));
+      const float gj = tanhf((cs[BN / 4] + pre[256 + u]) + p.bias[256 + u]);
+      const float gf = 1.f / (1.f + expf(-((cs[2 * (BN / 4)] + pre[512 + u]) + p.bias[512 + u] + 1.0f)));
+      const float go = 1.f / (1.f + expf(-((cs[3 * (BN / 4)] + pre[768 + u]) + p.bias[768 + u])));
+      const float c = p.c_prev[(size_t)row * 256 + u] * gf + gi * gj;
+      pre[u] = gi; pre[256 + u] = gj; pre[512 + u] = gf; pre[768 + u] = go;
+      p.c_out[(size_t)row * 256 + u] = c;
+      p.h_out[(size_t)row * p.ld_h + u] = tanhf(c) * go;
+    }
+    return;
+  }
   const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
                     (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
                     (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
 // 32x32 tiles through LDS so both sides stay coalesced.  Padding columns of dst are left as the caller zeroed them.
 __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, const float* __restrict__ src, int ld_src,
                                                            int transpose, unsigned short* __restrict__ dst, int ld_dst,
-                                                           long plane) {
+                                                           long plane, int row_perm) {
   __shared__ float t[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -430,7 +454,9 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, c
     if (r0 + y < rows && c0 + tx < cols) t[y][tx] = src[(size_t)(r0 + y) * ld_src + c0 + tx];
   __syncthreads();
   for (int y = ty; y < 32; y += 8) {
-    const int orow = transpose ? c0 + y : r0 + y, ocol = transpose ? r0 + tx : c0 + tx;
+    int orow = transpose ? c0 + y : r0 + y;
+    const int ocol = transpose ? r0 + tx : c0 + tx;
+    if (row_perm == 1) orow = ((orow & 255) >> 4) * 64 + (orow >> 8) * 16 + (orow & 15);   // LSTM gate interleave
     const bool ok = transpose ? (c0 + y < cols && r0 + tx < rows) : (r0 + y < rows && c0 + tx < cols);
     if (!ok) continue;
     float x = transpose ? t[tx][y] : t[y][tx];
@@ -461,6 +487,7 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   a.A = A; a.lda = lda; a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = C; a.ldc = ldc;
   a.bias = bias; a.mask = mask; a.ldm = ldm; a.flags = flags;
   a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
+  a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (blocks128 >= 384) {
     a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
@@ -473,6 +500,26 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
     if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
+  return unreal_launch_status();
+}
+
+int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint16_t* Wh3, int ldw, long plane_stride,
+                         float* gates, const float* bias, const float* c_prev, float* c_out, float* h_out, int ld_h,
+                         void* stream) {
+  if (rows <= 0 || !h_prev || !Wh3 || !gates || !bias || !c_prev || !c_out || !h_out) return UNREAL_EINVAL;
+  if (ld_hprev < 256 || ld_h < 256 || ldw < 256 || (ldw & 7) || (plane_stride & 7) || plane_stride < 1024L * ldw ||
+      (((uintptr_t)Wh3) & 15))
+    return UNREAL_EINVAL;
+  SplitArgs a;
+  a.M = rows; a.N = 1024; a.K = 256;
+  a.A = h_prev; a.lda = ld_hprev; a.W = Wh3; a.ldw = ldw; a.plane = plane_stride; a.C = gates; a.ldc = 1024;
+  a.bias = bias; a.mask = nullptr; a.ldm = 0; a.flags = 0;
+  a.vecA = ((ld_hprev & 3) == 0) && ((((uintptr_t)h_prev) & 15) == 0);
+  a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.ld_h = ld_h;
+  a.nbx = 16; a.nby = (rows + 63) / 64;
+  const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+  if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
 
@@ -494,14 +541,15 @@ int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const
   return unreal_launch_status();
 }
 
-int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, uint16_t* dst, int ld_dst,
-                        long plane_stride, void* stream) {
+int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
+                        int ld_dst, long plane_stride, void* stream) {
   if (rows <= 0 || cols <= 0 || !src || !dst || ld_src < cols) return UNREAL_EINVAL;
   const int orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
   if (ld_dst < ocols || plane_stride < (long)orows * ld_dst) return UNREAL_EINVAL;
+  if (row_perm != 0 && (row_perm != 1 || orows != 1024)) return UNREAL_EINVAL;
   dim3 grid((cols + 31) / 32, (rows + 31) / 32);
   hipLaunchKernelGGL(split_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, src, ld_src, transpose,
-                     dst, ld_dst, plane_stride);
+                     dst, ld_dst, plane_stride, row_perm);
   return unreal_launch_status();
 }
 

@@ -180,7 +180,7 @@ class UnrealModel(object):
             if self._use_lstm:
                 W = p["lstm_kernel"]
                 sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
-                          lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024),
+                          lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1),   # gate-interleaved
                           lstm_h_dgrad=S(W, 256, 1024, 1024, False, offset=K_x * 1024),
                           lstm_fc_dgrad=S(W, 256, 1024, 1024, False))
             if self._use_pixel_change:
@@ -272,8 +272,8 @@ class UnrealModel(object):
         h_prev = ws.h0 if t == 0 else ws.h[(t - 1) * B * 256:]
         c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
         g_t = ws.gates[t * B * 1024:]
-        ops.gemm_split_nt(B, 1024, 256, h_prev, 256, self.shadow["lstm_h_fwd"], g_t, 1024, flags=ops.GEMM_ACCUM)
-        ops.lstm_gates_fwd(B, g_t, p["lstm_bias"], c_prev, g_t, ws.c[t * B * 256:], ws.h[t * B * 256:])
+        ops.lstm_step_fwd(B, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[t * B * 256:],
+                          ws.h[t * B * 256:])
 
     def features(self, ws, row0=0):
         """(tensor, ld) of the features the heads read: LSTM outputs, or the fc output in FF mode."""

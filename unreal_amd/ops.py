@@ -280,8 +280,9 @@ class SplitWeights:
     """bf16x3 shadow of one weight matrix as unreal_gemm_f32_split_nt wants its W operand: planes[t][n][k], rows padded
     with zeros to a multiple of 32 k.  `refresh()` re-splits from the live fp32 weights (after an optimiser step)."""
 
-    def __init__(self, src, rows, cols, ld_src, transpose, offset=0):
+    def __init__(self, src, rows, cols, ld_src, transpose, offset=0, row_perm=0):
         self.src, self.rows, self.cols, self.ld_src, self.transpose, self.offset = src, rows, cols, ld_src, transpose, offset
+        self.row_perm = row_perm
         self.N, self.K = (cols, rows) if transpose else (rows, cols)
         self.ldw = (self.K + 31) // 32 * 32
         self.plane = self.N * self.ldw
@@ -290,14 +291,15 @@ class SplitWeights:
 
     def refresh(self):
         split_bf16x3(self.rows, self.cols, self.src[self.offset:], self.ld_src, self.transpose, self.planes, self.ldw,
-                     self.plane)
+                     self.plane, self.row_perm)
 
 
-def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane):
+def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, row_perm=0):
     _chk(src, "f32", (rows - 1) * ld_src + cols, "src")
     orows = cols if transpose else rows
     _chk(dst, "i16", 2 * plane + orows * ld_dst, "dst")
-    _call("unreal_split_bf16x3", rows, cols, ptr(src), ld_src, int(bool(transpose)), ptr(dst), ld_dst, plane)
+    _call("unreal_split_bf16x3", rows, cols, ptr(src), ld_src, int(bool(transpose)), int(row_perm), ptr(dst), ld_dst,
+          plane)
 
 
 def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0):
@@ -315,6 +317,18 @@ def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1):
     """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the bf16 matrix cores, split-K atomics into C)."""
     _chk(A, "f32", (K - 1) * lda + M, "A"); _chk(B, "f32", (K - 1) * ldb + N, "B"); _chk(C, "f32", (M - 1) * ldc + N, "C")
     _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, splitk)
+
+
+def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256):
+    """One BasicLSTMCell step: gates (in: x-half pre-activations, out: activated gates) += h_prev @ Wh, gate math fused.
+    Wh: SplitWeights(kernel recurrent rows, transpose=True, row_perm=1)."""
+    if Wh.N != 1024 or Wh.K != 256 or Wh.row_perm != 1:
+        raise ValueError("lstm_step_fwd needs the gate-interleaved [1024,256] shadow of the recurrent kernel rows")
+    _chk(h_prev, "f32", (rows - 1) * ld_hprev + 256, "h_prev"); _chk(gates, "f32", rows * 1024, "gates")
+    _chk(bias, "f32", 1024, "bias"); _chk(c_prev, "f32", rows * 256, "c_prev"); _chk(c_out, "f32", rows * 256, "c_out")
+    _chk(h_out, "f32", (rows - 1) * ld_h + 256, "h_out")
+    _call("unreal_lstm_step_fwd", rows, ptr(h_prev), ld_hprev, ptr(Wh.planes), Wh.ldw, Wh.plane, ptr(gates), ptr(bias),
+          ptr(c_prev), ptr(c_out), ptr(h_out), ld_h)
 
 
 def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):
