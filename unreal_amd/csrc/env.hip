@@ -55,17 +55,35 @@ __device__ __forceinline__ uint32_t render_byte(int idx, int ax, int ay) {
   return ch == 0 ? wall : (ch == 1 ? agent : 0u);
 }
 
-__device__ __forceinline__ void render_frame(uint8_t* dst, int ax, int ay) {
-  uint4* d4 = reinterpret_cast<uint4*>(dst);
+// The frame is the constant wall image plus the 12x12 agent block (channel 1).  A workgroup builds the wall image
+// ONCE in LDS (the per-byte index arithmetic below is ~250 VALU per 16 bytes: rendering every frame from scratch made
+// the step kernel VALU-bound at 1.6 TB/s) and streams it out for each of its actors; the agent block -- 12 rows of 36
+// contiguous bytes (0,1,0)x12, never on a wall cell -- is patched in afterwards as 9 dwords per row.
+constexpr int kActorsPerGroup = 16;
+
+__device__ __forceinline__ void build_wall_image(uint4* img) {
   for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) {
     uint32_t w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int base = c * 16 + k * 4;
-      w[k] = render_byte(base, ax, ay) | (render_byte(base + 1, ax, ay) << 8) |
-             (render_byte(base + 2, ax, ay) << 16) | (render_byte(base + 3, ax, ay) << 24);
+      w[k] = render_byte(base, -1, -1) | (render_byte(base + 1, -1, -1) << 8) | (render_byte(base + 2, -1, -1) << 16) |
+             (render_byte(base + 3, -1, -1) << 24);
     }
-    d4[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    img[c] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+// caller: __syncthreads() between the two (same workgroup, same addresses: the barrier orders the stores)
+__device__ __forceinline__ void render_walls(uint8_t* dst, const uint4* img) {
+  uint4* d4 = reinterpret_cast<uint4*>(dst);
+  for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) d4[c] = img[c];
+}
+__device__ __forceinline__ void render_agent(uint8_t* dst, int ax, int ay) {
+  if (threadIdx.x < 12 * 9) {
+    const int r = threadIdx.x / 9, w = threadIdx.x % 9;            // dword w of the 36-byte run: bytes 4w..4w+3
+    const uint32_t pat[3] = {0x00000100u, 0x01000001u, 0x00010000u};   // (0,1,0) repeated; byte 4w is channel w mod 3
+    reinterpret_cast<uint32_t*>(dst + (12 * ay + r) * FRAME_ROW_BYTES + 36 * ax)[w] = pat[w % 3];
   }
 }
 
@@ -101,69 +119,77 @@ struct StepArgs {
 };
 
 __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
-  const int b = blockIdx.x;
-  if (p.active && !p.active[b]) return;
+  __shared__ uint4 wall_img[FRAME_BYTES / 16];
+  build_wall_image(wall_img);
+  __syncthreads();
   const int H1 = p.H1;
-  const int x = p.pos[2 * b], y = p.pos[2 * b + 1];
-  const int a = p.actions[b];
-  const int cnt = p.count[b];
-  const int la = p.last_action[b];
-  const float lr = p.last_reward[b];
-  const int slot = cnt % H1;
-  const int prev_term = cnt > 0 ? p.r_terminal[(size_t)b * H1 + (cnt - 1) % H1] : 0;
-  float ep = p.track_score ? p.episode_reward[b] : 0.f;
+  for (int k = 0; k < kActorsPerGroup; ++k) {
+    const int b = blockIdx.x * kActorsPerGroup + k;
+    if (b >= p.B) break;
+    if (p.active && !p.active[b]) continue;
+    const int x = p.pos[2 * b], y = p.pos[2 * b + 1];
+    const int a = p.actions[b];
+    const int cnt = p.count[b];
+    const int la = p.last_action[b];
+    const float lr = p.last_reward[b];
+    const int slot = cnt % H1;
+    const int prev_term = cnt > 0 ? p.r_terminal[(size_t)b * H1 + (cnt - 1) % H1] : 0;
+    float ep = p.track_score ? p.episode_reward[b] : 0.f;
 
-  // _move (maze_environment.py:76-91)
-  int dx = (a == 3) - (a == 2), dy = (a == 1) - (a == 0);
-  int nx = x + dx, ny = y + dy;
-  bool clamped = nx < 0 || nx > 6 || ny < 0 || ny > 6;
-  nx = min(max(nx, 0), 6);
-  ny = min(max(ny, 0), 6);
-  bool hit_wall = is_wall(nx, ny);
-  if (hit_wall) { nx = x; ny = y; }
-  const bool hit = clamped || hit_wall;
-  const bool terminal = (nx == kGoalX && ny == kGoalY);
-  const float reward = terminal ? 1.f : (hit ? -1.f : 0.f);
-  __syncthreads();  // every thread has read the actor's state before anyone overwrites it
+    // _move (maze_environment.py:76-91)
+    int dx = (a == 3) - (a == 2), dy = (a == 1) - (a == 0);
+    int nx = x + dx, ny = y + dy;
+    bool clamped = nx < 0 || nx > 6 || ny < 0 || ny > 6;
+    nx = min(max(nx, 0), 6);
+    ny = min(max(ny, 0), 6);
+    bool hit_wall = is_wall(nx, ny);
+    if (hit_wall) { nx = x; ny = y; }
+    const bool hit = clamped || hit_wall;
+    const bool terminal = (nx == kGoalX && ny == kGoalY);
+    const float reward = terminal ? 1.f : (hit ? -1.f : 0.f);
 
-  const size_t base = (size_t)b * H1 + slot;
-  // pixel change between render(nx,ny) and render(x,y): only the two agent blocks differ (ch 1)
-  const bool moved = (nx != x) || (ny != y);
-  for (int c = threadIdx.x; c < PC_CELLS; c += blockDim.x) {
-    int i = c / 20, j = c - i * 20;
-    int s = 0;
-    if (moved) s = overlap1(y, i) * overlap1(x, j) + overlap1(ny, i) * overlap1(nx, j);
-    p.r_pc[base * PC_CELLS + c] = (float)s / 48.0f;
-  }
+    const size_t base = (size_t)b * H1 + slot;
+    // pixel change between render(nx,ny) and render(x,y): only the two agent blocks differ (ch 1)
+    const bool moved = (nx != x) || (ny != y);
+    for (int c = threadIdx.x; c < PC_CELLS; c += blockDim.x) {
+      int i = c / 20, j = c - i * 20;
+      int s = 0;
+      if (moved) s = overlap1(y, i) * overlap1(x, j) + overlap1(ny, i) * overlap1(nx, j);
+      p.r_pc[base * PC_CELLS + c] = (float)s / 48.0f;
+    }
 
-  const bool discard = terminal && cnt > 0 && prev_term;  // experience.py:64-67
-  const int ncnt = discard ? cnt : cnt + 1;
-  const bool reset = terminal && p.reset_on_terminal;
-  const int rx = reset ? kStartX : nx, ry = reset ? kStartY : ny;
-  const int nslot = ncnt % H1;
-  render_frame(p.frames + ((size_t)b * H1 + nslot) * FRAME_BYTES, rx, ry);
+    const bool discard = terminal && cnt > 0 && prev_term;  // experience.py:64-67
+    const int ncnt = discard ? cnt : cnt + 1;
+    const bool reset = terminal && p.reset_on_terminal;
+    const int rx = reset ? kStartX : nx, ry = reset ? kStartY : ny;
+    const int nslot = ncnt % H1;
+    uint8_t* dst = p.frames + ((size_t)b * H1 + nslot) * FRAME_BYTES;
+    render_walls(dst, wall_img);
+    __syncthreads();  // every thread has read the actor's state; wall stores precede the agent patch
+    render_agent(dst, rx, ry);
 
-  if (threadIdx.x == 0) {
-    p.r_reward[base] = reward;
-    p.r_action[base] = a;
-    p.r_terminal[base] = terminal ? 1 : 0;
-    p.r_last_action[base] = la;
-    p.r_last_reward[base] = lr;
-    p.pos[2 * b] = rx;
-    p.pos[2 * b + 1] = ry;
-    p.count[b] = ncnt;
-    p.last_action[b] = reset ? 0 : a;
-    p.last_reward[b] = reset ? 0.f : reward;
-    if (p.out_reward) p.out_reward[b] = reward;
-    if (p.out_terminal) p.out_terminal[b] = terminal ? 1 : 0;
-    if (p.track_score) {
-      ep += reward;
-      if (terminal) {
-        p.score_out[b] = ep;
-        p.score_valid[b] = 1;
-        ep = 0.f;
+    if (threadIdx.x == 0) {
+      p.r_reward[base] = reward;
+      p.r_action[base] = a;
+      p.r_terminal[base] = terminal ? 1 : 0;
+      p.r_last_action[base] = la;
+      p.r_last_reward[base] = lr;
+      p.pos[2 * b] = rx;
+      p.pos[2 * b + 1] = ry;
+      p.count[b] = ncnt;
+      p.last_action[b] = reset ? 0 : a;
+      p.last_reward[b] = reset ? 0.f : reward;
+      if (p.out_reward) p.out_reward[b] = reward;
+      if (p.out_terminal) p.out_terminal[b] = terminal ? 1 : 0;
+      if (p.track_score) {
+        ep += reward;
+        if (terminal) {
+          p.score_out[b] = ep;
+          p.score_valid[b] = 1;
+          ep = 0.f;
+        }
+        p.episode_reward[b] = ep;
       }
-      p.episode_reward[b] = ep;
     }
   }
 }
@@ -171,15 +197,24 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
 __global__ __launch_bounds__(256) void maze_reset_kernel(int B, int H1, const int* mask, int* pos,
                                                          int* last_action, float* last_reward,
                                                          const int* count, uint8_t* frames) {
-  const int b = blockIdx.x;
-  if (mask && !mask[b]) return;
-  const int slot = count[b] % H1;
-  render_frame(frames + ((size_t)b * H1 + slot) * FRAME_BYTES, kStartX, kStartY);
-  if (threadIdx.x == 0) {
-    pos[2 * b] = kStartX;
-    pos[2 * b + 1] = kStartY;
-    last_action[b] = 0;
-    last_reward[b] = 0.f;
+  __shared__ uint4 wall_img[FRAME_BYTES / 16];
+  build_wall_image(wall_img);
+  __syncthreads();
+  for (int k = 0; k < kActorsPerGroup; ++k) {
+    const int b = blockIdx.x * kActorsPerGroup + k;
+    if (b >= B) break;
+    if (mask && !mask[b]) continue;
+    const int slot = count[b] % H1;
+    uint8_t* dst = frames + ((size_t)b * H1 + slot) * FRAME_BYTES;
+    render_walls(dst, wall_img);
+    __syncthreads();
+    render_agent(dst, kStartX, kStartY);
+    if (threadIdx.x == 0) {
+      pos[2 * b] = kStartX;
+      pos[2 * b + 1] = kStartY;
+      last_action[b] = 0;
+      last_reward[b] = 0.f;
+    }
   }
 }
 
@@ -372,14 +407,14 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
   StepArgs p{B, H1, actions, active, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, reset_on_terminal, track_score};
-  hipLaunchKernelGGL(maze_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(maze_step_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
 int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
                       const int* count, uint8_t* frames, void* stream) {
   if (B <= 0 || H1 < 2 || !pos || !count || !frames) return UNREAL_EINVAL;
-  hipLaunchKernelGGL(maze_reset_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, H1, mask, pos,
+  hipLaunchKernelGGL(maze_reset_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, B, H1, mask, pos,
                      last_action, last_reward, count, frames);
   return unreal_launch_status();
 }
