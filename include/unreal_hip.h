@@ -122,9 +122,11 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
                              int flags, void* stream);
 /* wgrad on the same scheme: C[M,N] += A[K,M]^T * B[K,N] (k = the row index of both activations), split-K with fp32
  * atomics into the caller's (pre-initialised) C.  Both operands are split while they are transposed into LDS.
- * lda, ldb multiples of 4 and A, B 16-byte aligned (else -22: use unreal_gemm_f32 transA=1). */
+ * lda, ldb multiples of 4 and A, B 16-byte aligned (else -22: use unreal_gemm_f32 transA=1).
+ * colsum (nullable): colsum[n] += sum_k B[k][n], the bias gradient that belongs to this weight gradient, summed
+ * from the B tiles the kernel stages anyway (saves a separate pass over B). */
 int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                             int splitk, void* stream);
+                             float* colsum, int splitk, void* stream);
 /* bf16x3 shadow of a weight matrix src[rows][cols]: dst[t][r][c] (transpose = 0) or dst[t][c][r] (transpose = 1),
  * t = 0..2 the bf16 terms (sum of the three == src to 2^-24 relative).  dst padding is left untouched (zero it once).
  * Refreshed after every RMSProp step / checkpoint restore. */

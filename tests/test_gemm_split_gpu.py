@@ -67,8 +67,14 @@ def test_split_tn_wgrad_matches_fp64(M, N, K, sk):
     ref = A[:, :M].T @ B[:, :N]
     scale = np.abs(A[:, :M]).T @ np.abs(B[:, :N])
     C = dev(C0)
-    ops.gemm_split_tn(M, N, K, dev(A), lda, dev(B), ldb, C, ldc, splitk=sk)
+    cs0 = rs.uniform(-1, 1, size=N + 2)
+    cs = dev(cs0)
+    ops.gemm_split_tn(M, N, K, dev(A), lda, dev(B), ldb, C, ldc, splitk=sk, colsum=cs)
     got = C.cpu().double().numpy()
+    # fused bias gradient: column sums of B on top of the previous contents, nothing past N touched
+    want_cs = cs0[:N].astype(np.float32) + B[:, :N].astype(np.float32).astype(np.float64).sum(0)
+    np.testing.assert_allclose(cs.cpu().numpy()[:N], want_cs, atol=3e-7 * np.abs(B[:, :N]).sum(0).max() + 1e-5, rtol=0)
+    np.testing.assert_array_equal(cs.cpu().numpy()[N:], cs0[N:].astype(np.float32))
     err = np.abs(got[:, :N] - (ref + C0[:, :N].astype(np.float32)))
     # bound: the fp32 ACCUMULATION rounding (a CPU emulation of this case gives 2.1e-7 * scale for the split scheme and
     # 2.8e-7 for a plain fp32 chain; the split itself contributes 4e-9) -- the comparison with the fp32 kernel below is

@@ -328,6 +328,7 @@ struct SplitTnArgs {
   const float* A; int lda;
   const float* B; int ldb;
   float* C; int ldc;
+  float* colsum;                       // nullable: colsum[n] += sum_k B[k][n] (the bias gradient that goes with dW)
   int ntx, nty, splitk, ktiles_per_split;
 };
 
@@ -368,6 +369,17 @@ __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&r
   }
 }
 
+// column sums of the B tile a thread holds (rows past K masked), weighted by w (0 or 1)
+__device__ __forceinline__ void tn_colsum_acc(const f32x4 (&reg)[4], int klim, float w, float (&cs)[4]) {
+  const int k4 = threadIdx.x >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const float wk = (4 * k4 + kk < klim) ? w : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[j] = fmaf(wk, reg[kk][j], cs[j]);
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
   constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
@@ -400,10 +412,15 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[4], rb[4];
+  // bias gradient: the row of tiles by == 0 also sums the columns of every B tile it stages (multiplying by 0
+  // elsewhere keeps the K loop one basic block)
+  const float csw = (p.colsum != nullptr && by == 0) ? 1.f : 0.f;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   tn_piece_load(p.A, p.lda, p.K, m0, kt0 * BK, ra);
   tn_piece_load(p.B, p.ldb, p.K, n0, kt0 * BK, rb);
   tn_piece_store<BM>(As, ra, p.K - kt0 * BK);
   tn_piece_store<BN>(Bs, rb, p.K - kt0 * BK);
+  tn_colsum_acc(rb, p.K - kt0 * BK, csw, cs);
   {
     const int k1 = (kt0 + min(1, nkt - 1)) * BK;
     tn_piece_load(p.A, p.lda, p.K, m0, k1, ra);
@@ -422,11 +439,25 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
     tn_piece_store<BM>(As, ra, p.K - kcur);
     tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
     tn_piece_store<BN>(Bs, rb, p.K - kcur);
+    tn_colsum_acc(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);      // the last pass re-stages a tile already counted
     tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
     mma_frags<TM, TN>(af, bf, acc);
     __syncthreads();                                   // tile `it + 1` is visible
   }
 
+  if (csw != 0.f) {      // block-uniform; the K loop ended with a barrier, so the operand LDS is free
+    float* red = reinterpret_cast<float*>(smem);
+    const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[k4 * BN + 4 * m4 + j] = cs[j];
+    __syncthreads();
+    if (threadIdx.x < BN && n0 + threadIdx.x < p.N) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += red[k * BN + threadIdx.x];
+      atomicAdd(p.colsum + n0 + threadIdx.x, v);
+    }
+  }
   // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); 32 lanes = 128 B per atomic
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -524,11 +555,11 @@ int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint
 }
 
 int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                             int splitk, void* stream) {
+                             float* colsum, int splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return UNREAL_EINVAL;
   if ((lda & 3) || (ldb & 3) || lda < 4 || ldb < 4 || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return UNREAL_EINVAL;
   SplitTnArgs a;
-  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.colsum = colsum;
   a.ntx = (N + 127) / 128; a.nty = (M + 127) / 128;
   const int nk = (K + BK - 1) / BK;
   if (splitk < 1) splitk = 1;

@@ -311,7 +311,7 @@ class UnrealModel(object):
             # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
             # last_action_reward rows by the small-N outer-product kernel (no padded third tile)
             ops.gemm_split_tn(256, 1024, rows, ws.xcat, self.xld, gws.d_gates, 1024, dW, 1024,
-                              splitk=_splitk(256, 1024, rows))
+                              splitk=_splitk(256, 1024, rows), colsum=g["lstm_bias"])     # + bias gradient
             c0 = 256
             for w in _small_chunks(K_x - 256):         # last action, last reward (and objective) rows
                 ops.linear_small_bwd(rows, 1024, w, gws.d_gates, 1024, ws.xcat[c0:], self.xld, None, None, 0, False,
@@ -324,7 +324,6 @@ class UnrealModel(object):
             if h0_nonzero:
                 ops.gemm_split_tn(256, 1024, B, ws.h0, 256, gws.d_gates, 1024, dW[K_x * 1024:], 1024,
                               splitk=_splitk(256, 1024, B))
-            ops.colsum(rows, 1024, gws.d_gates, 1024, g["lstm_bias"])
             ops.gemm_split_nt(rows, 256, 1024, gws.d_gates, 1024, sh["lstm_fc_dgrad"], gws.d_fc, 256, mask=ws.xcat,
                               ldm=self.xld, flags=ops.GEMM_RELU_MASK)
             d_fc = gws.d_fc
@@ -332,8 +331,7 @@ class UnrealModel(object):
             ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, self.xld)
             d_fc = d_feat
         ops.gemm_split_tn(2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256,
-                              splitk=_splitk(2592, 256, rows))
-        ops.colsum(rows, 256, d_fc, 256, g["b_base_fc1"])
+                              splitk=_splitk(2592, 256, rows), colsum=g["b_base_fc1"])
         ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
                           flags=ops.GEMM_RELU_MASK)
         ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,

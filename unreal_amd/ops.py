@@ -313,10 +313,12 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
           ptr(mask), ldm, flags)
 
 
-def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1):
-    """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the bf16 matrix cores, split-K atomics into C)."""
+def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None):
+    """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the bf16 matrix cores, split-K atomics into C);
+    colsum[N] += column sums of B (the bias gradient of the same layer) when given."""
     _chk(A, "f32", (K - 1) * lda + M, "A"); _chk(B, "f32", (K - 1) * ldb + N, "B"); _chk(C, "f32", (M - 1) * ldc + N, "C")
-    _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, splitk)
+    _chk(colsum, "f32", N, "colsum", optional=True)
+    _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(colsum), splitk)
 
 
 def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256):

@@ -302,8 +302,7 @@ class Trainer(object):
                           g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592,
-                              splitk=_splitk(256, 2592, rows))
-        ops.colsum(rows, 2592, d_hp, 2592, g["b_pc_fc1"])
+                              splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"])
         ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, net.shadow["pc_fc1_dgrad"], gws.d_feat, 256)
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
 
