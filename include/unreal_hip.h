@@ -119,7 +119,10 @@ int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
  * unreal_gemm_f32 except ATOMIC.  Used for the forward and dgrad GEMMs of the dense layers. */
 int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw,
                              long plane_stride, float* C, int ldc, const float* bias, const float* mask, int ldm,
-                             int flags, void* stream);
+                             int flags, int splitk, void* stream);
+/* splitk > 1 needs UNREAL_GEMM_ATOMIC (K slabs added into a pre-initialised C with fp32 atomics; no ReLU / mask /
+ * ACCUM then).  Measured at the per-step shapes (4096 rows): 4096x256x2592 61 -> 50 us at splitk 4, 4096x256x1024
+ * slower (the atomics cost what the extra workgroups buy), so the trainer keeps splitk = 1 there. */
 /* wgrad on the same scheme: C[M,N] += A[K,M]^T * B[K,N] (k = the row index of both activations), split-K with fp32
  * atomics into the caller's (pre-initialised) C.  Both operands are split while they are transposed into LDS.
  * lda, ldb multiples of 4 and A, B 16-byte aligned (else -22: use unreal_gemm_f32 transA=1).

@@ -51,6 +51,15 @@ def test_split_gemm_matches_fp64(M, N, K):
     Cx = torch.zeros(M, ldc, device=DEV)
     ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, mask=dev(msk), ldm=N, flags=ops.GEMM_RELU_MASK)
     assert (np.abs(Cx[:, :N].cpu().double().numpy() - ref * (msk > 0)) <= 3e-7 * scale + 1e-6).all()
+    # split-K: K slabs added with atomics on top of C (+ bias once)
+    for sk in (2, 5):
+        Cx = dev(C0)
+        ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, bias=dev(bias), flags=ops.GEMM_ATOMIC, splitk=sk)
+        got = Cx.cpu().double().numpy()
+        assert (np.abs(got[:, :N] - (ref + bias + C0[:, :N].astype(np.float32))) <= 3e-7 * scale + 3e-6).all()
+        np.testing.assert_array_equal(got[:, N:], C0[:, N:].astype(np.float32))
+    with pytest.raises(RuntimeError):
+        ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, splitk=2)                    # split-K needs ATOMIC
 
 
 @pytest.mark.parametrize("M,N,K,sk", [(2592, 256, 4000, 9), (256, 1024, 333, 1), (261, 1024, 70, 2), (256, 2592, 2100, 25),

@@ -82,6 +82,11 @@ def main():
             A_ = rnd(M * lda); Bt_ = ops.SplitWeights(rnd(N * K), N, K, K, False); C_ = torch.zeros(M * N, device=DEV)
             report("split_nt %s M=%d N=%d K=%d" % (name, M, N, K),
                    timeit(lambda: ops.gemm_split_nt(M, N, K, A_, lda, Bt_, C_, N)), flop=2.0 * M * N * K)
+            if M == B and K >= 1024:
+                for sk in (2, 4, 8):
+                    report("split_nt %s splitk=%d (atomic)" % (name, sk),
+                           timeit(lambda: ops.gemm_split_nt(M, N, K, A_, lda, Bt_, C_, N, flags=ops.GEMM_ATOMIC, splitk=sk)),
+                           flop=2.0 * M * N * K)
             del A_, Bt_, C_
 
     if not FILT or FILT in "split gemm tn":

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int ROW_B = 80;                    // bytes per LDS row: 32 bf16 + 16 pad
-constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_RELU_MASK = 8;
+constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_ATOMIC = 4, FLAG_RELU_MASK = 8;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -48,6 +48,7 @@ struct SplitArgs {
   int flags;
   int vecA;
   int nbx, nby;
+  int splitk, ktiles_per_split;        // > 1 only with FLAG_ATOMIC: K slabs added into C with fp32 atomics
   // fused LSTM step (EPI == 1): C is the gate buffer [M][1024] (in: input-half pre-activations, out: activated gates)
   const float* c_prev; float* c_out; float* h_out; int ld_h;
 };
@@ -164,10 +165,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   // XCD-aware block order: workgroup L runs on XCD L % 8; slot s = L / 8 of that XCD sweeps x first, and the row
   // panels are dealt to the XCDs round-robin, so the nbx blocks that share one A panel follow each other on one L2.
   const int L = blockIdx.x, xcd = L & 7, s = L >> 3;
-  const int bx = s % p.nbx, by = (s / p.nbx) * 8 + xcd;
+  const int slab = s % p.splitk, s2 = s / p.splitk;     // K slabs of one tile follow each other on the XCD
+  const int bx = s2 % p.nbx, by = (s2 / p.nbx) * 8 + xcd;
   if (by >= p.nby) return;
   const int m0 = by * BM, n0 = bx * BN;
-  const int nkt = (p.K + BK - 1) / BK;
+  const int kt_base = slab * p.ktiles_per_split;
+  const int nkt = min((p.K + BK - 1) / BK - kt_base, p.ktiles_per_split);
+  if (nkt <= 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   f32x4 ra[2][PA];      // DEEP: A pieces travel TWO tiles ahead (set it&1 holds tile it+1); W pieces always one (L2)
   u32x4 rw[PW];
   const int shift = (int)((unsigned)by * 7u % (unsigned)nkt);    // de-synchronise the panel sweeps of different rows
-#define KT_AT(i) (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift)
+#define KT_AT(i) (kt_base + (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift))
   {
     const int k0 = KT_AT(0) * BK;
 #pragma unroll
@@ -245,6 +249,23 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   }
 #undef SPLIT_NT_TILE
 
+  if (EPI == 0 && (p.flags & FLAG_ATOMIC)) {
+    // split-K: partial tile added into C (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + li;
+        if (col >= p.N) continue;
+        const float bv = (p.bias && slab == 0) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r] + bv);
+        }
+      }
+    return;
+  }
   // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip)
   constexpr int CLD = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
@@ -505,29 +526,39 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, c
 extern "C" {
 
 int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw, long plane_stride,
-                             float* C, int ldc, const float* bias, const float* mask, int ldm, int flags, void* stream) {
+                             float* C, int ldc, const float* bias, const float* mask, int ldm, int flags, int splitk,
+                             void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W3 || !C) return UNREAL_EINVAL;
   const int kpad = (K + BK - 1) / BK * BK;
   if (lda < K || ldw < kpad || (ldw & 7) || (plane_stride & 7) || plane_stride < (long)N * ldw || ldc < N ||
       (((uintptr_t)W3) & 15))
     return UNREAL_EINVAL;
-  if (flags & ~(FLAG_RELU | FLAG_ACCUM | FLAG_RELU_MASK)) return UNREAL_EINVAL;
+  if (flags & ~(FLAG_RELU | FLAG_ACCUM | FLAG_ATOMIC | FLAG_RELU_MASK)) return UNREAL_EINVAL;
   if ((flags & FLAG_RELU_MASK) && (!mask || ldm < N)) return UNREAL_EINVAL;
+  if ((flags & FLAG_ATOMIC) && (flags & (FLAG_RELU | FLAG_RELU_MASK | FLAG_ACCUM))) return UNREAL_EINVAL;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && !(flags & FLAG_ATOMIC)) return UNREAL_EINVAL;
   SplitArgs a;
   a.M = M; a.N = N; a.K = K;
   a.A = A; a.lda = lda; a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = C; a.ldc = ldc;
   a.bias = bias; a.mask = mask; a.ldm = ldm; a.flags = flags;
   a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
-  const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  {
+    const int nk = (K + BK - 1) / BK;
+    if (splitk > nk) splitk = nk;
+    a.ktiles_per_split = (nk + splitk - 1) / splitk;
+    a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+  }
+  const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
   if (blocks128 >= 384) {
     a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
-    const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+    const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
     if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
-    const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+    const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
     if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
@@ -547,6 +578,7 @@ int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint
   a.bias = bias; a.mask = nullptr; a.ldm = 0; a.flags = 0;
   a.vecA = ((ld_hprev & 3) == 0) && ((((uintptr_t)h_prev) & 15) == 0);
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.ld_h = ld_h;
+  a.splitk = 1; a.ktiles_per_split = 256 / BK;
   a.nbx = 16; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
   if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -302,7 +302,7 @@ def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, row_per
           plane)
 
 
-def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0):
+def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):
     """C = A[M,K] @ W[N,K]^T (fp32-grade, 3 x bf16 split operands on the bf16 matrix cores); W is a SplitWeights."""
     if W.N != N or W.K != K:
         raise ValueError("split weights are [%d,%d], GEMM wants [%d,%d]" % (W.N, W.K, N, K))
@@ -310,7 +310,7 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
     _chk(bias, "f32", N, "bias", optional=True)
     _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
     _call("unreal_gemm_f32_split_nt", M, N, K, ptr(A), lda, ptr(W.planes), W.ldw, W.plane, ptr(C), ldc, ptr(bias),
-          ptr(mask), ldm, flags)
+          ptr(mask), ldm, flags, splitk)
 
 
 def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None):
