@@ -17,9 +17,10 @@ SHAPES = (("fc_fwd", 81920, 256, 2592), ("pc_fc1", 81920, 2592, 256), ("d_fc", 8
 
 def build(bits):
     so = os.path.join(OUT, "split_%d.so" % bits)
+    extra = []
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DSPLIT_ABLATE=%d" % bits,
-                           os.path.join(ROOT, "unreal_amd/csrc/gemm_split.hip"), "-o", so] + sys.argv[1:])
+                           "-DSPLIT_ABLATE=%d" % (bits % 100),
+                           os.path.join(ROOT, "unreal_amd/csrc/gemm_split.hip"), "-o", so] + extra + sys.argv[1:])
     return ctypes.CDLL(so)
 
 
@@ -29,13 +30,13 @@ def main():
         f = lib.unreal_gemm_f32_split_nt
         f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_long,
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                           ctypes.c_int, ctypes.c_void_p]
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         line = "ablate=%d" % bits
         for name, M, N, K in SHAPES:
             A = torch.randn(M * K, device="cuda"); C = torch.zeros(M * N, device="cuda")
             B = torch.randn(3 * N * K, device="cuda").to(torch.bfloat16)
             st = torch.cuda.current_stream().cuda_stream
-            run = lambda: f(M, N, K, A.data_ptr(), K, B.data_ptr(), K, N * K, C.data_ptr(), N, None, None, 0, 0, st)
+            run = lambda: f(M, N, K, A.data_ptr(), K, B.data_ptr(), K, N * K, C.data_ptr(), N, None, None, 0, 0, 1, st)
             for _ in range(2):
                 run()
             torch.cuda.synchronize()
