@@ -158,6 +158,10 @@ int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, 
                             const float* W, float* dX, int lddx, int accumulate_dx, float* dW, int dw_stride_k,
                             int dw_stride_n, float* db, void* stream);
 int unreal_softmax_sample(int rows, int A, float* logits_pi, int ld, const double* u, int* action, void* stream);
+/* one rollout step of the policy in one launch: pi = softmax(X Wp + bp), v = X Wv + bv, action ~ pi (u null: arg max);
+ * bit-identical to unreal_linear_small_fwd x2 + unreal_softmax_sample (K = 256 features, A in {3, 4, 6}) */
+int unreal_policy_step(int rows, int A, const float* X, int ldx, const float* Wp, const float* bp, const float* Wv,
+                       const float* bv, const double* u, float* pi_out, float* v_out, int* action, void* stream);
 int unreal_base_loss_grad(int rows, int A, const float* pi, int ld_pi, const float* v, const int* action,
                           const float* adv, const float* R, const int* active, float entropy_beta, float grad_scale,
                           float* dlogits, float* dv, float* losses /*[3]: policy, value, entropy*/, void* stream);

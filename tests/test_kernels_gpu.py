@@ -696,3 +696,27 @@ def test_objective_put_and_fill():
         assert (got == 9.0).all()
     with pytest.raises(ValueError):
         ops.objective_put(ops.Ring(2, 3, DEV), torch.zeros(2, device=DEV))
+
+
+@pytest.mark.parametrize("A", [3, 4, 6])
+def test_policy_step_is_the_three_kernel_path(A):
+    """unreal_policy_step == linear_small_fwd (policy) + linear_small_fwd (value) + softmax_sample, bit for bit,
+    sampled and greedy, with a padded feature stride."""
+    from unreal_amd import ops
+    rows, ld = 1000, 264
+    rs = np.random.RandomState(A)
+    X = torch.as_tensor(rs.normal(size=rows * ld), dtype=torch.float32).to(DEV)
+    Wp = torch.as_tensor(rs.normal(size=256 * A) * 0.3, dtype=torch.float32).to(DEV)
+    bp = torch.as_tensor(rs.normal(size=A), dtype=torch.float32).to(DEV)
+    Wv = torch.as_tensor(rs.normal(size=256) * 0.1, dtype=torch.float32).to(DEV)
+    bv = torch.as_tensor(rs.normal(size=1), dtype=torch.float32).to(DEV)
+    u = torch.as_tensor(rs.random_sample(rows)).to(DEV)
+    for uu in (u, None):
+        pi0, v0, a0 = torch.zeros(rows * A, device=DEV), torch.zeros(rows, device=DEV), torch.zeros(rows, dtype=torch.int32, device=DEV)
+        ops.linear_small_fwd(rows, 256, A, X, ld, Wp, bp, pi0, A)
+        ops.linear_small_fwd(rows, 256, 1, X, ld, Wv, bv, v0, 1)
+        ops.softmax_sample(rows, A, pi0, A, uu, a0)
+        pi1, v1, a1 = torch.zeros(rows * A, device=DEV), torch.zeros(rows, device=DEV), torch.zeros(rows, dtype=torch.int32, device=DEV)
+        ops.policy_step(rows, A, X, ld, Wp, bp, Wv, bv, uu, pi1, v1, a1)
+        assert torch.equal(pi0, pi1) and torch.equal(v0, v1) and torch.equal(a0, a1)
+    assert len(torch.unique(a1)) > 1

@@ -149,6 +149,66 @@ __global__ void softmax_sample_kernel(int rows, int A, float* __restrict__ logit
   }
 }
 
+// One rollout step of the policy: pi = softmax(X Wp + bp), v = X Wv + bv, action ~ pi (inverse CDF in fp64, or
+// arg max when u == null) in ONE launch; one wave per row.  The arithmetic is that of linear_small_fwd_kernel<A>,
+// linear_small_fwd_kernel<1> and softmax_sample_kernel, operation for operation, so the results are bit-identical to
+// the three-kernel path (model/model.py:358-377, train/trainer.py:147-148).
+template <int A>
+__global__ __launch_bounds__(256) void policy_step_kernel(int rows, const float* __restrict__ X, int ldx,
+                                                          const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                          const float* __restrict__ Wv, const float* __restrict__ bv,
+                                                          const double* __restrict__ u, float* __restrict__ pi_out,
+                                                          float* __restrict__ v_out, int* __restrict__ action) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float acc[A], accv = 0.f;
+#pragma unroll
+  for (int n = 0; n < A; ++n) acc[n] = 0.f;
+  const float* x = X + (size_t)row * ldx;
+  for (int k = lane; k < LSTM_N; k += 64) {
+    float xv = x[k];
+#pragma unroll
+    for (int n = 0; n < A; ++n) acc[n] += xv * Wp[(size_t)k * A + n];
+    accv += xv * Wv[k];
+  }
+#pragma unroll
+  for (int n = 0; n < A; ++n) acc[n] = wave_sum(acc[n]);
+  accv = wave_sum(accv);
+  if (lane != 0) return;
+  v_out[row] = accv + bv[0];
+  float p[A];
+#pragma unroll
+  for (int n = 0; n < A; ++n) p[n] = acc[n] + bp[n];
+  float m = p[0];
+#pragma unroll
+  for (int a = 1; a < A; ++a) m = fmaxf(m, p[a]);
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < A; ++a) { float e = expf(p[a] - m); p[a] = e; s += e; }
+#pragma unroll
+  for (int a = 0; a < A; ++a) { p[a] = p[a] / s; pi_out[(size_t)row * A + a] = p[a]; }
+  if (u) {
+    double tot = 0.0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) tot += (double)p[a];
+    double run = 0.0, uu = u[row];
+    int act = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      run += (double)p[a];
+      if (run / tot <= uu) act = a + 1;     // searchsorted(cdf, u, side='right')
+    }
+    action[row] = min(act, A - 1);
+  } else {                                  // greedy (np.argmax: first maximum), for evaluation
+    int best = 0;
+#pragma unroll
+    for (int a = 1; a < A; ++a)
+      if (p[a] > p[best]) best = a;
+    action[row] = best;
+  }
+}
+
 // A3C loss + gradient wrt logits and value.  losses[0..2] += (policy_loss, value_loss, entropy) * loss_scale
 __global__ __launch_bounds__(256) void base_loss_grad_kernel(int rows, int A, const float* __restrict__ pi, int ld_pi,
                                                              const float* __restrict__ v, const int* __restrict__ action,
@@ -341,6 +401,20 @@ int unreal_linear_small_bwd(int rows, int K, int NOUT, const float* X, int ldx, 
 int unreal_softmax_sample(int rows, int A, float* logits_pi, int ld, const double* u, int* action, void* stream) {
   if (rows <= 0 || A <= 0 || A > 8 || !logits_pi || ld < A) return UNREAL_EINVAL;
   hipLaunchKernelGGL(softmax_sample_kernel, GRID1(rows), rows, A, logits_pi, ld, u, action);
+  return unreal_launch_status();
+}
+
+int unreal_policy_step(int rows, int A, const float* X, int ldx, const float* Wp, const float* bp, const float* Wv,
+                       const float* bv, const double* u, float* pi_out, float* v_out, int* action, void* stream) {
+  if (rows <= 0 || !X || !Wp || !bp || !Wv || !bv || !pi_out || !v_out || !action || ldx < LSTM_N) return UNREAL_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  switch (A) {
+    case 3: hipLaunchKernelGGL((policy_step_kernel<3>), grid, block, 0, st, rows, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, action); break;
+    case 4: hipLaunchKernelGGL((policy_step_kernel<4>), grid, block, 0, st, rows, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, action); break;
+    case 6: hipLaunchKernelGGL((policy_step_kernel<6>), grid, block, 0, st, rows, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, action); break;
+    default: return UNREAL_EINVAL;
+  }
   return unreal_launch_status();
 }
 

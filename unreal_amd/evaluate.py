@@ -42,12 +42,9 @@ class Evaluate(object):
             if net._use_lstm:
                 net.lstm_step(ws, 0, B)
             feat, ld = net.features(ws, 0)
-            net.heads_forward(B, feat, ld, self.pi, self.v)
-            if self.greedy:
-                ops.softmax_sample(B, A, self.pi, A, None, self.actions)
-            else:
+            if not self.greedy:
                 self.draws.uniform(self.u)
-                ops.softmax_sample(B, A, self.pi, A, self.u, self.actions)
+            net.policy_step(B, feat, ld, None if self.greedy else self.u, self.pi, self.v, self.actions)
             self.env.process(self.actions, None, self.rewards, self.terminals, reset_on_terminal=True,
                              track_score=True)
             if net._use_lstm:                      # carry the state; zero it where the episode ended

@@ -342,6 +342,12 @@ class UnrealModel(object):
         ops.linear_small_fwd(rows, 256, A, feat, ld, p["W_base_fc_p"], p["b_base_fc_p"], pi_out, A)
         ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)
 
+    def policy_step(self, rows, feat, ld, u, pi_out, v_out, actions_out):
+        """heads_forward + softmax / action draw in one launch (u None: greedy)."""
+        p = self.p
+        ops.policy_step(rows, self._action_size, feat, ld, p["W_base_fc_p"], p["b_base_fc_p"], p["W_base_fc_v"],
+                        p["b_base_fc_v"], u, pi_out, v_out, actions_out)
+
     def value_forward(self, rows, feat, ld, v_out):
         p = self.p
         ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)

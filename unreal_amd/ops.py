@@ -366,6 +366,15 @@ def linear_small_bwd(rows, K, NOUT, X, ldx, dO, ldo, W, dX, lddx, accumulate_dx,
           int(accumulate_dx), ptr(dW), int(dw_stride_k), int(dw_stride_n), ptr(db))
 
 
+def policy_step(rows, A, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, action):
+    """pi, v and the sampled (u) or greedy (u None) action of `rows` feature rows in one launch."""
+    _chk(X, "f32", (rows - 1) * ldx + 256, "X"); _chk(Wp, "f32", 256 * A); _chk(bp, "f32", A); _chk(Wv, "f32", 256)
+    _chk(bv, "f32", 1); _chk(u, "f64", rows, "u", optional=True); _chk(pi_out, "f32", rows * A); _chk(v_out, "f32", rows)
+    _chk(action, "i32", rows)
+    _call("unreal_policy_step", rows, A, ptr(X), ldx, ptr(Wp), ptr(bp), ptr(Wv), ptr(bv), ptr(u), ptr(pi_out), ptr(v_out),
+          ptr(action))
+
+
 def softmax_sample(rows, A, logits_pi, ld, u=None, action=None):
     _chk(logits_pi, "f32", (rows - 1) * ld + A); _chk(u, "f64", rows, optional=True)
     _chk(action, "i32", rows, optional=True)

@@ -185,8 +185,7 @@ class Trainer(object):
         if self.use_lstm:
             net.lstm_step(ws, t, B)
         feat, ld = net.features(ws, t * B)
-        net.heads_forward(B, feat, ld, pi_out, v_out)
-        ops.softmax_sample(B, A, pi_out, A, u, actions_out)
+        net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
 
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
