@@ -47,6 +47,23 @@ def main():
             e1.record(); torch.cuda.synchronize()
             line += "  %s %.3f ms" % (name, e0.elapsed_time(e1) / 5)
             del A, B, C
+        g = lib.unreal_gemm_f32_split_tn
+        g.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        for name, M, N, K, sk in (("tn_fc1", 2592, 256, 81920, 25), ("tn_lstm", 256, 1024, 81920, 64)):
+            A = torch.randn(K * M, device="cuda"); B = torch.randn(K * N, device="cuda"); C = torch.zeros(M * N, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            run = lambda: g(M, N, K, A.data_ptr(), M, B.data_ptr(), N, C.data_ptr(), N, None, sk, st)
+            for _ in range(2):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            line += "  %s %.3f ms" % (name, e0.elapsed_time(e1) / 5)
+            del A, B, C
         print(line, flush=True)
 
 

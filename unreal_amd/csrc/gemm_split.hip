@@ -71,18 +71,33 @@ __device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int l
   return v;
 }
 
-// 4 fp32 values -> three bf16x4 terms (8 bytes each): round to nearest, residual exact in fp32, twice.  The residuals
-// are taken with scalar v_sub_f32 on purpose: the 2-vector form compiles to v_pk_add_f32, and packed fp32 VALU issues
-// slowly next to MFMAs (A/B on one device: 81920x256x2592 0.80 -> 0.77 ms).
+// 4 fp32 values -> three bf16x4 terms (8 bytes each): round to nearest, residual exact in fp32, twice.
+// PACKED selects how the residuals are subtracted: as 2-vectors (v_pk_add_f32) or with scalar v_sub_f32.  Same values
+// either way; A/B on one device: the NT kernels (one operand split) are 1-5 % faster with the scalar form, the TN
+// kernel (both operands split, twice the VALU) 5 % faster with the packed one.
+template <bool PACKED>
 __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float x3, u32x2 (&pl)[3]) {
+  if (PACKED) {
+    f32x2 x01 = {x0, x1}, x23 = {x2, x3};
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const bf16x2 h01 = __builtin_convertvector((f32x2){x0, x1}, bf16x2), h23 = __builtin_convertvector((f32x2){x2, x3}, bf16x2);
-    const unsigned int w01 = __builtin_bit_cast(unsigned int, h01), w23 = __builtin_bit_cast(unsigned int, h23);
-    pl[t] = (u32x2){w01, w23};
-    if (t < 2) {
-      x0 -= __uint_as_float(w01 << 16); x1 -= __uint_as_float(w01 & 0xffff0000u);
-      x2 -= __uint_as_float(w23 << 16); x3 -= __uint_as_float(w23 & 0xffff0000u);
+    for (int t = 0; t < 3; ++t) {
+      const bf16x2 h01 = __builtin_convertvector(x01, bf16x2), h23 = __builtin_convertvector(x23, bf16x2);
+      pl[t] = (u32x2){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+      if (t < 2) {
+        x01 = x01 - __builtin_convertvector(h01, f32x2);
+        x23 = x23 - __builtin_convertvector(h23, f32x2);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bf16x2 h01 = __builtin_convertvector((f32x2){x0, x1}, bf16x2), h23 = __builtin_convertvector((f32x2){x2, x3}, bf16x2);
+      const unsigned int w01 = __builtin_bit_cast(unsigned int, h01), w23 = __builtin_bit_cast(unsigned int, h23);
+      pl[t] = (u32x2){w01, w23};
+      if (t < 2) {
+        x0 -= __uint_as_float(w01 << 16); x1 -= __uint_as_float(w01 & 0xffff0000u);
+        x2 -= __uint_as_float(w23 << 16); x3 -= __uint_as_float(w23 & 0xffff0000u);
+      }
     }
   }
 }
@@ -95,7 +110,7 @@ __device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int kli
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? v[e] : 0.f;
   u32x2 pl[3];
-  split4_terms(v[0], v[1], v[2], v[3], pl);
+  split4_terms<false>(v[0], v[1], v[2], v[3], pl);
 #pragma unroll
   for (int t = 0; t < 3; ++t)
     *reinterpret_cast<u32x2*>(S + (t * ROWS + r) * ROW_B + k * 2) = pl[t];
@@ -380,7 +395,7 @@ __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&r
   for (int j = 0; j < 4; ++j) {
     const int r = 4 * m4 + j;
     u32x2 pl[3];
-    split4_terms(ok[0] ? reg[0][j] : 0.f, ok[1] ? reg[1][j] : 0.f, ok[2] ? reg[2][j] : 0.f, ok[3] ? reg[3][j] : 0.f, pl);
+    split4_terms<true>(ok[0] ? reg[0][j] : 0.f, ok[1] ? reg[1][j] : 0.f, ok[2] ? reg[2][j] : 0.f, ok[3] ? reg[3][j] : 0.f, pl);
     const int off = (((k4 >> 1) ^ ((r >> 4) & 3)) * 2 + (k4 & 1)) * 8;       // swizzled 16-B chunk, 8-B half
 #pragma unroll
     for (int t = 0; t < 3; ++t)
