@@ -10,7 +10,8 @@
 // ONE GEMM of M = 100 base positions (a,b), K = 4 taps x 32 channels, N = 4 parities x (1+A) channels = 20 of 32
 // columns (per-parity GEMMs would fill 5 of 16).  Operands are split into three bf16 terms when they are staged into
 // LDS (hp per frame, the weights once per workgroup) and multiplied as six term-pair v_mfma_f32_16x16x32_bf16, the
-// scheme and error level of csrc/gemm_split.hip.  Backward (below) still runs per parity on the fp32 MFMA.
+// scheme and error level of csrc/gemm_split.hip.  The backward pass uses the same split planes; its weight gradient reduces
+// over positions (the row index of the LDS images), so its operands come through transposed LDS reads.
 // Same group/LDS organisation and MFMA operand convention as encoder.hip: the next frame's inputs are
 // fetched into registers behind the current frame's math, outputs leave through LDS in 16 B/lane rows.
 #include "common.h"
@@ -298,53 +299,122 @@ struct PcBwdArgs {
   float* dWv; float* dbv; float* dWa; float* dba;
 };
 
+// Backward on the split-operand scheme of the forward (three bf16 planes per operand, six term-pair MFMAs):
+//   dgrad  d_hp[pos][ci] = sum_{ky,kx,co} d_dec[2y+ky][2x+kx][co] W[ky][kx][co][ci]
+//          per ky one 32-deep step: k = (kx, co) is 64 contiguous bytes of the d_dec planes ([400 pos][8 co] bf16);
+//   wgrad  dW[(ky,kx,co)][ci] += sum_pos d_dec[2y+ky][2x+kx][co] hp[pos][ci]
+//          the reduction index is the position = the row index of both LDS images: both operands come through
+//          ds_read_b64_tr_b16 (4 rows x 16 columns, transposed in flight); a block row of d_dec is the 32 bytes of two
+//          neighbouring output positions (kx, kx+1) x 8 co, i.e. exactly one 16-row MFMA tile.
+typedef short s16x4p __attribute__((ext_vector_type(4)));
+typedef short s16x8p __attribute__((ext_vector_type(8)));
+constexpr int DDP_ROW = 16;                          // bytes per output position in a d_dec plane (8 co bf16)
+constexpr int DDP_PLANE = (PC_CELLS + 4) * DDP_ROW;  // + 4 zero rows (positions past the 81 of the last k step)
+constexpr int WBP_PLANE = 4 * 32 * WDP_ROW;          // [ky][ci(32)] rows of 32 (kx,co) bf16 + pad = 10240
+constexpr int BWD_GRP_BYTES = 3 * HPP_PLANE + 3 * DDP_PLANE + F2_DIM * 4;   // hp planes | d_dec planes | d_hp staging
+
+__device__ __forceinline__ bf16x8 tr_pair_p(const unsigned char* a0, const unsigned char* a1) {
+  typedef s16x4p __attribute__((address_space(3))) * lds_p;
+  const s16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  const s16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
+  const s16x8p v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// one fp32 value -> its three bf16 terms (round to nearest, residuals exact)
+__device__ __forceinline__ void split1p(float x, unsigned short (&t)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const __bf16 h = (__bf16)x;
+    t[k] = __builtin_bit_cast(unsigned short, h);
+    x -= (float)h;
+  }
+}
+
 __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
-  constexpr int GRP_BYTES = HP_ROWS * HP_LD * 4 + PC_CELLS * DEC_LD_B * 4 + F2_DIM * 4;
-  constexpr int WB_ELEMS = 4 * 2 * 4 * 32 * 4;   // [ky][c][q][ci(32)][s]; kx = q, co = 4c + s
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + WB_ELEMS * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BWD_GRP_BYTES + 3 * WBP_PLANE];
   const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  float* hp = reinterpret_cast<float*>(smem + grp * GRP_BYTES);
-  float* dec = hp + HP_ROWS * HP_LD;
-  float* dhs = dec + PC_CELLS * DEC_LD_B;        // staged d_hp of the frame: [81][32] dense
-  float* wb = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
+  unsigned char* hpp = smem + grp * BWD_GRP_BYTES;
+  unsigned char* ddp = hpp + 3 * HPP_PLANE;
+  float* dhs = reinterpret_cast<float*>(ddp + 3 * DDP_PLANE);      // staged d_hp of the frame: [81][32] dense
+  unsigned char* wbp = smem + 2 * BWD_GRP_BYTES;
   const int A = p.A, CO = 1 + p.A;
 
-  for (int e = threadIdx.x; e < WB_ELEMS; e += 512) {
-    int s = e & 3, ci = (e >> 2) & 31, qq = (e >> 7) & 3, c = (e >> 9) & 1, ky = e >> 10;
-    int co = 4 * c + s;
+  // weights -> bf16x3 planes [plane][ky][ci(32)][k = kx*8 + co (32, co >= CO zero)]
+  for (int e = threadIdx.x; e < 4 * 32 * 32; e += 512) {
+    const int k = e & 31, ci = (e >> 5) & 31, ky = e >> 10;
+    const int kx = k >> 3, co = k & 7;
     float v = 0.f;
-    if (co == 0) v = p.Wv[(ky * 4 + qq) * 32 + ci];
-    else if (co <= A) v = p.Wa[((ky * 4 + qq) * A + (co - 1)) * 32 + ci];
-    wb[e] = v;
+    if (co == 0) v = p.Wv[(ky * 4 + kx) * 32 + ci];
+    else if (co <= A) v = p.Wa[((ky * 4 + kx) * A + (co - 1)) * 32 + ci];
+    unsigned short t[3];
+    split1p(v, t);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      reinterpret_cast<unsigned short*>(wbp + pl * WBP_PLANE + (ky * 32 + ci) * WDP_ROW)[k] = t[pl];
   }
-  for (int e = gtid; e < 3 * HP_LD; e += 256) hp[C2_POS * HP_LD + e] = 0.f;
-  // zero the co >= CO padding columns of dec once (never rewritten)
-  for (int e = gtid; e < PC_CELLS * DEC_LD_B; e += 256) dec[e] = 0.f;
+  for (int e = gtid; e < 3 * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the three hp planes
+    const int t = e / (3 * HPP_ROW / 4), w = e % (3 * HPP_ROW / 4);
+    reinterpret_cast<uint32_t*>(hpp + t * HPP_PLANE + C2_POS * HPP_ROW)[w] = 0u;
+  }
+  // d_dec planes: the co >= CO padding columns and the 4 extra rows stay zero (never rewritten)
+  for (int e = gtid; e < 3 * DDP_PLANE / 4; e += 256) reinterpret_cast<uint32_t*>(ddp)[e] = 0u;
 
-  f32x4 aw[2][2];          // dW tiles: ky = gw, kxh = 0..1 (kx = 2kxh + (i>>3), co = i&7), nt = 0..1
+  f32x4 aw[2][2];          // dW tiles: ky = gw, kxh = 0..1 (kx = 2kxh + (row>>3), co = row&7), nt = 0..1
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) aw[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float adb[8];
+  float adb = 0.f;         // bias gradient: this thread's d_dec elements all belong to ONE channel only if CO | 4 ...
+  float adbk[8];           // ... so keep one accumulator per channel, indexed statically below
 #pragma unroll
-  for (int k = 0; k < 8; ++k) adb[k] = 0.f;
+  for (int k = 0; k < 8; ++k) adbk[k] = 0.f;
+  (void)adb;
   const int nt = gw & 1;
-  const int akx = i >> 3, aco = i & 7;
   const int n_dd4 = PC_CELLS * CO / 4;           // f32x4 in one frame's d_dec
+  const int qq = i >> 2, pp = i & 3;             // transposed reads: lane (4qq + pp) of a 16-lane group addresses block row qq
 
   const int stride = gridDim.x * 2;
   f32x4 pre_hp[HP_V], pre_dd[DD_V];
-  __syncthreads();   // dec zero-fill visible before the first scatter
+
+  // scatter one frame's d_dec (registers, [400][CO] dense) into the planes + bias-gradient sums
+  auto stage_dd = [&](const f32x4 (&dd)[DD_V]) {
+#pragma unroll
+    for (int c = 0; c < DD_V; ++c) {
+      const int id = gtid + 256 * c;
+      if (id < n_dd4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int el = 4 * id + e;
+          const int pos = el / CO, co = el - pos * CO;
+          const float v = dd[c][e];
+          unsigned short t[3];
+          split1p(v, t);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            reinterpret_cast<unsigned short*>(ddp + pl * DDP_PLANE + pos * DDP_ROW)[co] = t[pl];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) adbk[k] += (co == k) ? v : 0.f;
+        }
+      }
+    }
+  };
+
+  __syncthreads();   // zero fills visible before the first scatter
   {
     const int n0 = blockIdx.x * 2 + grp;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
-      hp_store(hp, gtid, pre_hp);
-      const float* dsrc = p.d_dec + (size_t)n0 * PC_CELLS * CO;
-      for (int e = gtid; e < PC_CELLS * CO; e += 256) dec[(e / CO) * DEC_LD_B + (e % CO)] = dsrc[e];
+      hp_store_planes(hpp, gtid, pre_hp);
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(p.d_dec + (size_t)n0 * PC_CELLS * CO);
+#pragma unroll
+      for (int c = 0; c < DD_V; ++c) {
+        int id = gtid + 256 * c;
+        pre_dd[c] = s4[id < n_dd4 ? id : 0];
+      }
+      stage_dd(pre_dd);
     }
   }
   for (int base = blockIdx.x * 2; base < p.N; base += stride) {
@@ -352,7 +422,7 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     const bool valid = n < p.N;
     const int nn = n + stride;
     const bool has_next = nn < p.N;
-    __syncthreads();  // [S0] hp / dec of frame n staged; dhs drained
+    __syncthreads();  // [S0] hp / d_dec planes of frame n staged; dhs drained
     if (has_next) {
       hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre_hp);
       const f32x4* s4 = reinterpret_cast<const f32x4*>(p.d_dec + (size_t)nn * PC_CELLS * CO);
@@ -363,77 +433,78 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       }
     }
     if (valid) {
-      for (int pos = gtid; pos < PC_CELLS; pos += 256)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) adb[k] += dec[pos * DEC_LD_B + k];      // padding columns are zero
-      // (a) dgrad: d_hp[pos][ci] = sum_{ky,kx,co} d_dec[2y+ky][2x+kx][co] W[ky][kx][co][ci]
+      // (a) dgrad: wave gw owns position tiles (gw>>1) + 2jj (jj = 0..2) and channel half nt
       {
         f32x4 acc[3];
         int abase[3];
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
           acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          int pos = min(((gw >> 1) + 2 * jj) * 16 + i, C2_POS - 1);
-          abase[jj] = ((2 * (pos / 9)) * 20 + 2 * (pos % 9) + q) * DEC_LD_B;
+          const int pos = min(((gw >> 1) + 2 * jj) * 16 + i, C2_POS - 1);
+          abase[jj] = ((2 * (pos / 9)) * 20 + 2 * (pos % 9) + q) * DDP_ROW;      // k chunk q = kx
         }
 #pragma unroll
-        for (int ky = 0; ky < 4; ++ky)
+        for (int ky = 0; ky < 4; ++ky) {
+          bf16x8 bw[3];
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const f32x4 bw = *reinterpret_cast<const f32x4*>(wb + ((((ky * 2 + c) * 4 + q) * 32) + nt * 16 + i) * 4);
-            f32x4 av[3];
+          for (int pl = 0; pl < 3; ++pl)
+            bw[pl] = *reinterpret_cast<const bf16x8*>(wbp + pl * WBP_PLANE + (ky * 32 + nt * 16 + i) * WDP_ROW + 16 * q);
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj)
-              av[jj] = *reinterpret_cast<const f32x4*>(dec + abase[jj] + ky * 20 * DEC_LD_B + 4 * c);
+          for (int jj = 0; jj < 3; ++jj) {
+            bf16x8 av[3];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-              for (int jj = 0; jj < 3; ++jj) acc[jj] = MFMA16(av[jj][s], bw[s], acc[jj]);
+            for (int pl = 0; pl < 3; ++pl)
+              av[pl] = *reinterpret_cast<const bf16x8*>(ddp + pl * DDP_PLANE + abase[jj] + ky * 20 * DDP_ROW);
+            PC_SPLIT_MMA(av, bw, acc[jj]);
           }
+        }
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            int pos = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
+            const int pos = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
             if (pos < C2_POS) {
-              int ci = nt * 16 + i;
-              dhs[pos * 32 + ci] = hp[pos * HP_LD + ci] > 0.f ? acc[jj][r] : 0.f;
+              const int ci = nt * 16 + i;
+              // relu mask of pc_fc1: hp > 0 <=> its leading bf16 term > 0
+              const unsigned short h0 = reinterpret_cast<const unsigned short*>(hpp + pos * HPP_ROW)[ci];
+              dhs[pos * 32 + ci] = (h0 != 0 && !(h0 & 0x8000)) ? acc[jj][r] : 0.f;
             }
           }
       }
-      // (b) wgrad: dW[(ky,kx,co)][ci] += sum_pos d_dec[2y+ky][2x+kx][co] * hp[pos][ci]
-#pragma unroll 3
-      for (int st = 0; st < 21; ++st) {
-        const int kp = min(4 * st + q, C2_POS - 1);
-        const int kpb = 4 * st + q;                      // rows 81..83 of hp are zero
-        const float b0 = hp[kpb * HP_LD + i], b1 = hp[kpb * HP_LD + 16 + i];
-        const int ab = ((2 * (kp / 9) + gw) * 20 + 2 * (kp % 9) + akx) * DEC_LD_B + aco;
+      // (b) wgrad: wave gw = ky; K = 81 positions in 3 steps of 32 (rows past 80 read zero rows)
+#pragma unroll 1
+      for (int ks = 0; ks < 3; ++ks) {
+        const int p0 = 32 * ks + 8 * q + qq, p1 = p0 + 4;
+        const unsigned char* b0 = hpp + min(p0, C2_POS) * HPP_ROW + 8 * pp;
+        const unsigned char* b1 = hpp + min(p1, C2_POS) * HPP_ROW + 8 * pp;
+        bf16x8 bf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bf[t][pl] = tr_pair_p(b0 + pl * HPP_PLANE + 32 * t, b1 + pl * HPP_PLANE + 32 * t);
+        // d_dec block row of position p: output rows (2y+ky, 2x + 2kxh .. +1) x 8 co = 32 contiguous bytes
+        const int r0 = p0 < C2_POS ? (2 * (p0 / 9) + gw) * 20 + 2 * (p0 % 9) : PC_CELLS;
+        const int r1 = p1 < C2_POS ? (2 * (p1 / 9) + gw) * 20 + 2 * (p1 % 9) : PC_CELLS;
 #pragma unroll
         for (int kxh = 0; kxh < 2; ++kxh) {
-          const float av = dec[ab + 2 * kxh * DEC_LD_B];
-          aw[kxh][0] = MFMA16(av, b0, aw[kxh][0]);
-          aw[kxh][1] = MFMA16(av, b1, aw[kxh][1]);
+          bf16x8 af[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            af[pl] = tr_pair_p(ddp + pl * DDP_PLANE + (r0 + 2 * kxh) * DDP_ROW + 8 * pp,
+                               ddp + pl * DDP_PLANE + (r1 + 2 * kxh) * DDP_ROW + 8 * pp);
+          PC_SPLIT_MMA(af, bf[0], aw[kxh][0]);
+          PC_SPLIT_MMA(af, bf[1], aw[kxh][1]);
         }
       }
     }
-    __syncthreads();  // [S1] all reads of hp / dec done; dhs of frame n complete
+    __syncthreads();  // [S1] all reads of the planes done; dhs of frame n complete
     if (valid) {      // d_hp leaves in full 128 B lines
       f32x4* dst = reinterpret_cast<f32x4*>(p.d_hp + (size_t)n * F2_DIM);
       for (int id = gtid; id < F2_DIM / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dhs)[id];
     }
     if (has_next) {
-      hp_store(hp, gtid, pre_hp);
-#pragma unroll
-      for (int c = 0; c < DD_V; ++c) {
-        int id = gtid + 256 * c;
-        if (id < n_dd4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            int el = 4 * id + e;
-            dec[(el / CO) * DEC_LD_B + (el % CO)] = pre_dd[c][e];
-          }
-        }
-      }
+      hp_store_planes(hpp, gtid, pre_hp);
+      stage_dd(pre_dd);
     }
   }
 
@@ -451,7 +522,7 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    float v = wave_sum(adb[k]);
+    float v = wave_sum(adbk[k]);
     if (lane == 0 && k < CO) {
       if (k == 0) atomicAdd(p.dbv, v);
       else atomicAdd(p.dba + (k - 1), v);
