@@ -35,7 +35,8 @@ def build_library(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(LIB_DIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + os.environ.get("UNREAL_HIPCC_FLAGS", "").split() + \
+              ["-c", s, "-o", o]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
