@@ -170,3 +170,12 @@ def test_environment_objective_size_registry():
     from unreal_amd.model.model import param_spec, xcat_ld
     spec = dict((n, s) for n, s, _ in param_spec(3, 7))
     assert spec["lstm_kernel"] == (256 + 3 + 1 + 7 + 256, 1024) and xcat_ld(3, 7) == 272 and xcat_ld(4, 0) == 264
+
+
+def test_wgrad_splitk_is_a_multiple_of_8_at_trainer_shapes():
+    """The wgrad kernel deals whole K slabs to the 8 XCDs: slab counts that are not a multiple of 8 leave XCDs idle."""
+    from unreal_amd.model.model import _splitk
+    for M, N, K in ((2592, 256, 81920), (256, 1024, 81920), (256, 1024, 77824), (256, 2592, 81920), (256, 1024, 4096)):
+        sk = _splitk(M, N, K)
+        assert sk % 8 == 0 and 8 <= sk <= (K + 31) // 32 // 4
+    assert _splitk(256, 1024, 60) == 1 and _splitk(2592, 256, 40) == 1        # tiny test batches: no split
