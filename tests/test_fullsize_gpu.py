@@ -15,6 +15,9 @@ B, H, T = 4096, 2000, 20
 def trained():
     import argparse
     from bench import build_trainer
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 200 * 2 ** 30:
+        pytest.skip("full-size replay ring needs ~195 GB of HBM, %.0f GB free" % (free / 2 ** 30))
     args = argparse.Namespace(actors=B, history=H)
     flags, net, tr = build_trainer(args, 0, 1, torch.device(DEV))
     while not tr._full:
