@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of full-UNREAL `Trainer.process()` on maze 84x84 (BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: under an outer `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE already set: this process IS one rank), or typed as is -- then this process is
+only a launcher: before anything touches the GPU it starts N fresh rank processes of itself
+(unreal_amd.parallel.launch_ranks), relays rank 0's JSON line and exits with the worst child code.
 
 A "step" is one `Trainer.process()` call: every actor of the rank is advanced by n_step_TD = 20
 environment steps (HIP env kernel writing straight into the HBM replay ring), then one UNREAL update
@@ -103,13 +108,17 @@ def main():
     ap.add_argument("--timed-kernel", default="unreal_encoder_bwd")
     args = ap.parse_args()
 
-    from unreal_amd import parallel, ops
+    from unreal_amd import parallel
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher only: nothing in this process has touched (or will touch) the GPU
+        sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    from unreal_amd import ops
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
-    dev_index = int(os.environ.get("UNREAL_FORCE_DEVICE", local_rank))   # rehearsal: several ranks on one GPU
+    dev_index = parallel.device_index(local_rank)      # UNREAL_FORCE_DEVICE: several ranks rehearse on one GPU
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
 
@@ -143,7 +152,9 @@ def main():
     tot_steps, tot_eps, tot_score = parallel.sum_over_ranks([steps_local, episodes, score_sum], device)
     losses = tr._publish_losses()
 
+    backend = parallel.backend_name()
     if rank != 0:
+        parallel.shutdown()
         return
     value = tot_steps / elapsed
     frames_per_launch = kt["units"] / max(kt["launches"], 1)
@@ -169,7 +180,7 @@ def main():
                                "n_step_TD=%d, replay history %d/actor (uint8 HBM ring)" % (args.actors, T, args.history),
                    "actors_per_gpu": args.actors, "global_actors": args.actors * world,
                    "env_steps_per_call": tot_steps / args.steps, "parallelism": "actors sharded x%d, flat-gradient "
-                   "all-reduce" % world if world > 1 else "single GPU", "replay_fill_s": t_fill,
+                   "all-reduce (%s)" % (world, backend) if world > 1 else "single GPU", "replay_fill_s": t_fill,
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
         "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -188,7 +199,8 @@ def main():
                                "sample": "%d env-steps in %.1f s: %d Python threads x full-UNREAL process() "
                                          "(oracle/trainer.py, PyTorch-CPU fp32, 1 intra-op thread each), replay "
                                          "history %d/thread (fill untimed)" % (s, el, args.cpu_threads, hist_cpu)}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

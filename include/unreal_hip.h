@@ -53,9 +53,14 @@ int unreal_hostfed_reset(int B, int H1, const int* mask, const uint8_t* staged, 
 int unreal_pixel_change_u8(int N, const uint8_t* frames, const int* idx_new, const int* idx_old,
                            float denom, float* out, void* stream);
 
-/* ---- counter RNG (stands in for the shared numpy RandomState of main.py:213) ---------- */
-int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, double* out, void* stream);
-int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int high, int* out, void* stream);
+/* ---- counter RNG (stands in for the shared numpy RandomState of main.py:213) ----------
+ * out[i] = draw number (i / row_len) * row_stride + col0 + i % row_len of Philox stream (seed, stream_id): with
+ * row_len = actors of this rank, row_stride = actors of all ranks, col0 = first actor of this rank, a sharded job
+ * draws exactly what one process holding every actor would (row_len = row_stride = n, col0 = 0: a plain stream). */
+int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, int row_len, int row_stride, int col0,
+                          double* out, void* stream);
+int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int row_len, int row_stride, int col0, int high,
+                          int* out, void* stream);
 
 /* ---- replay sampling (train/experience.py:100-118, 121-153; train/trainer.py:427-434) ------------ */
 int unreal_replay_sample_seq(int B, int H, int H1, int L, const int* start_draw, const int* count,

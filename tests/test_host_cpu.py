@@ -115,10 +115,14 @@ def test_learning_rate_schedule_and_draw_streams():
     assert t._anneal_learning_rate(0) == lr0
     assert abs(t._anneal_learning_rate(6600000) - lr0 / 2) < 1e-12
     assert t._anneal_learning_rate(14000000) == 0.0
-    a, b = PhiloxDraws(1, rank=0), PhiloxDraws(1, rank=1)
-    sa = {a._next() for _ in range(1000)}
-    sb = {b._next() for _ in range(1000)}
-    assert not (sa & sb) and len(sa) == 1000
+    # ranks share the stream ids and read disjoint columns [rank*B, (rank+1)*B) of each global draw
+    a, b = PhiloxDraws(1, rank=0, batch=8, world_size=2), PhiloxDraws(1, rank=1, batch=8, world_size=2)
+    sa = [a._next() for _ in range(1000)]
+    sb = [b._next() for _ in range(1000)]
+    assert sa == sb and len(set(sa)) == 1000
+    assert (a.batch, a.stride, a.col0) == (8, 16, 0) and (b.batch, b.stride, b.col0) == (8, 16, 8)
+    p = PhiloxDraws(1)
+    assert (p.batch, p.stride, p.col0) == (None, None, 0)
 
 
 def test_oracle_indoor_contract_and_objective_concat():

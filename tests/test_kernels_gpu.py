@@ -661,6 +661,21 @@ def test_philox(ops):
     ops.philox_uniform(0, 0, a[:1])
     want = ((0x6627e8d5 >> 5) * 67108864.0 + (0xe169c58d >> 6)) / 9007199254740992.0
     assert float(a.cpu()[0]) == want
+    # sharded view: rank r of W reads columns [r*B, (r+1)*B) of every [.., W*B] row of the global draw
+    T, B, W = 5, 37, 3
+    g = torch.zeros(T * B * W, dtype=torch.float64, device=DEV)
+    gi = torch.zeros(T * B * W, dtype=torch.int32, device=DEV)
+    ops.philox_uniform(11, 9, g, B * W)
+    ops.philox_randint(11, 10, 1000, gi, B * W)
+    for rk in range(W):
+        s = torch.zeros(T * B, dtype=torch.float64, device=DEV)
+        si = torch.zeros(T * B, dtype=torch.int32, device=DEV)
+        ops.philox_uniform(11, 9, s, B, B * W, rk * B)
+        ops.philox_randint(11, 10, 1000, si, B, B * W, rk * B)
+        assert torch.equal(s.view(T, B), g.view(T, B * W)[:, rk * B:(rk + 1) * B])
+        assert torch.equal(si.view(T, B), gi.view(T, B * W)[:, rk * B:(rk + 1) * B])
+    with pytest.raises(ValueError):
+        ops.philox_uniform(11, 9, g, B, B, 1)            # columns outside the row
 
 
 def test_objective_put_and_fill():

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 MAX_TO_KEEP = 20
-_NAME = re.compile(r"^(?P<prefix>[A-Za-z_]+)-(?P<score>\d*)-(?P<t>\d+)\.pt$")
+# prefix: anything (the caller's `name` may hold '-', digits or dots); the last two dash-separated fields are parsed
+_NAME = re.compile(r"^(?P<prefix>.+)-(?P<score>\d*)-(?P<t>\d+)\.pt$")
 
 
 def checkpoint_name(best_score, global_t, name=""):
@@ -30,8 +31,9 @@ def list_checkpoints(checkpoint_dir):
     out = []
     for p in glob.glob(os.path.join(checkpoint_dir, "*.pt")):
         m = _NAME.match(os.path.basename(p))
-        if m:
-            out.append((int(m.group("t")), p))
+        if m is None:            # never skip silently: a mis-named file would be ignored by restore AND by pruning
+            raise ValueError("%s does not follow <name>-<score digits>-<global_t>.pt" % p)
+        out.append((int(m.group("t")), p))
     return sorted(out)
 
 

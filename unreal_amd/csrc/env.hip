@@ -376,20 +376,29 @@ __device__ __forceinline__ void philox4x32_10(uint64_t seed, uint64_t index, uin
   out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
 }
 
-__global__ void philox_uniform_kernel(uint64_t seed, uint64_t stream, int n, double* out) {
+// Element i of a rank's draw is element (i / row_len) * row_stride + col0 + i % row_len of the GLOBAL draw: with
+// row_len = this rank's actors, row_stride = all actors and col0 = the rank's first actor, a job sharded over W ranks
+// draws exactly what one process holding every actor would (row_len = row_stride = n, col0 = 0: a plain stream).
+__device__ __forceinline__ uint64_t philox_index(int i, int row_len, int row_stride, int col0) {
+  return (uint64_t)(i / row_len) * (uint64_t)row_stride + (uint64_t)col0 + (uint64_t)(i % row_len);
+}
+
+__global__ void philox_uniform_kernel(uint64_t seed, uint64_t stream, int n, int row_len, int row_stride, int col0,
+                                      double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t r[4];
-  philox4x32_10(seed, (uint64_t)i, stream, r);
+  philox4x32_10(seed, philox_index(i, row_len, row_stride, col0), stream, r);
   // 53-bit uniform in [0,1), same construction as numpy's random_sample
   out[i] = ((double)(r[0] >> 5) * 67108864.0 + (double)(r[1] >> 6)) / 9007199254740992.0;
 }
 
-__global__ void philox_randint_kernel(uint64_t seed, uint64_t stream, int n, int high, int* out) {
+__global__ void philox_randint_kernel(uint64_t seed, uint64_t stream, int n, int row_len, int row_stride, int col0,
+                                      int high, int* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t r[4];
-  philox4x32_10(seed, (uint64_t)i, stream, r);
+  philox4x32_10(seed, philox_index(i, row_len, row_stride, col0), stream, r);
   out[i] = (int)(((uint64_t)r[0] * (uint64_t)high) >> 32);
 }
 
@@ -454,17 +463,21 @@ int unreal_pixel_change_u8(int N, const uint8_t* frames, const int* idx_new, con
   return unreal_launch_status();
 }
 
-int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, double* out, void* stream) {
-  if (n <= 0 || !out) return UNREAL_EINVAL;
+int unreal_philox_uniform(uint64_t seed, uint64_t stream_id, int n, int row_len, int row_stride, int col0,
+                          double* out, void* stream) {
+  if (n <= 0 || !out || row_len <= 0 || row_stride < row_len || col0 < 0 || col0 + row_len > row_stride)
+    return UNREAL_EINVAL;
   hipLaunchKernelGGL(philox_uniform_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
-                     stream_id, n, out);
+                     stream_id, n, row_len, row_stride, col0, out);
   return unreal_launch_status();
 }
 
-int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int high, int* out, void* stream) {
-  if (n <= 0 || high <= 0 || !out) return UNREAL_EINVAL;
+int unreal_philox_randint(uint64_t seed, uint64_t stream_id, int n, int row_len, int row_stride, int col0, int high,
+                          int* out, void* stream) {
+  if (n <= 0 || high <= 0 || !out || row_len <= 0 || row_stride < row_len || col0 < 0 || col0 + row_len > row_stride)
+    return UNREAL_EINVAL;
   hipLaunchKernelGGL(philox_randint_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
-                     stream_id, n, high, out);
+                     stream_id, n, row_len, row_stride, col0, high, out);
   return unreal_launch_status();
 }
 

@@ -25,6 +25,7 @@ class HostFedEnvironment(object):
         self.objective_size = int(objective_size)
         self.reward_divisor = float(reward_divisor)
         self.pc_denom = 48.0 * frame_max
+        self.frame_scale = 1.0 / frame_max          # lab_environment.py:99-102: state = obs / 255
         self.device = torch.device(device)
         self.ring = ops.Ring(batch, history_size, self.device, objective_size=self.objective_size)
         if self.objective_size:
@@ -36,10 +37,21 @@ class HostFedEnvironment(object):
         self._staged = torch.empty(batch * ops.FRAME_BYTES, dtype=torch.uint8, device=self.device)
         self._rewards = torch.empty(batch, dtype=torch.float32, device=self.device)
         self._terminals = torch.empty(batch, dtype=torch.int32, device=self.device)
+        self._h2d_done = None
         self.reset()
 
     def get_action_size(self):
         return self.action_size
+
+    def _wait_staging(self):
+        """The pinned staging buffers may be rewritten only after the H2D copies that read them have finished."""
+        if self._h2d_done is not None:
+            self._h2d_done.synchronize()
+
+    def _mark_staging(self):
+        if self._h2d_done is None:
+            self._h2d_done = torch.cuda.Event()
+        self._h2d_done.record()
 
     def _stage(self, frames):
         self._h_frames.copy_(torch.from_numpy(np.ascontiguousarray(frames)))
@@ -54,10 +66,12 @@ class HostFedEnvironment(object):
         m = None if mask is None else mask.cpu().numpy()
         out = self.sim.reset(m)
         frames, objectives = out if self.objective_size else (out, None)
+        self._wait_staging()
         self._stage(frames)
         ops.hostfed_reset(self.ring, self._staged, mask)
         if self.objective_size:
             self._stage_objective(objectives, mask)
+        self._mark_staging()
 
     def process(self, actions, active=None, out_reward=None, out_terminal=None, reset_on_terminal=True,
                 track_score=False):
@@ -67,6 +81,7 @@ class HostFedEnvironment(object):
         frames, rewards, terminals = out[:3]
         if self.reward_divisor != 1.0:                  # indoor_environment.py:111
             rewards = (rewards.astype(np.float64) / self.reward_divisor).astype(np.float32)
+        self._wait_staging()
         self._stage(frames)
         self._h_rewards.copy_(torch.from_numpy(rewards))
         self._h_terminals.copy_(torch.from_numpy(terminals))
@@ -76,6 +91,7 @@ class HostFedEnvironment(object):
                          out_terminal, reset_on_terminal, track_score, self.clip_reward, self.pc_denom)
         if self.objective_size:
             self._stage_objective(out[3], active)
+        self._mark_staging()
 
     def stop(self):
         pass

@@ -13,6 +13,7 @@ from . import environment
 
 class BatchedMazeEnvironment(object):
     ACTION_SIZE = 4
+    frame_scale = 1.0          # ring bytes are the pixel values themselves (0 / 1)
 
     def __init__(self, batch, history_size, device="cuda:0"):
         self.B = batch

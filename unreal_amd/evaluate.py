@@ -19,6 +19,7 @@ class Evaluate(object):
         self.draws = draws if draws is not None else PhiloxDraws(seed)
         B, A = self.B, network._action_size
         self.env = BatchedMazeEnvironment(B, 2, self.device)
+        network.bind_frame_scale(self.env.frame_scale)
         self.ws = PathWS(B, B, self.device, save_c1=False, lstm=network._use_lstm, xld=network.xld)
         z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)
         self.pi, self.v = z(B * A, torch.float32), z(B, torch.float32)

@@ -135,7 +135,7 @@ class UnrealModel(object):
     def __init__(self, action_size, objective_size, thread_index, use_lstm, use_pixel_change,
                  use_value_replay, use_reward_prediction, pixel_change_lambda, entropy_beta, device,
                  segnet_param_dict=None, image_shape=(84, 84), is_training=True, n_classes=0,
-                 segnet_lambda=1.0, dropout=0.0, for_display=False, frame_scale=1.0, seed=0):
+                 segnet_lambda=1.0, dropout=0.0, for_display=False, frame_scale=None, seed=0):
         if objective_size < 0:
             raise ValueError("objective_size must be >= 0")
         if segnet_param_dict is not None and segnet_param_dict.get("segnet_mode", 0) not in (0, None):
@@ -154,7 +154,10 @@ class UnrealModel(object):
         self._use_reward_prediction = use_reward_prediction
         self._pixel_change_lambda = pixel_change_lambda
         self._entropy_beta = entropy_beta
-        self.frame_scale = float(frame_scale)
+        # value of one stored frame byte: 1 for the maze's 0/1 bytes, 1/255 for host-fed uint8 observations.  None =
+        # "whatever the environment stores": Trainer.prepare() / Evaluate set it from environment.frame_scale.
+        self._frame_scale_given = frame_scale is not None
+        self.frame_scale = 1.0 if frame_scale is None else float(frame_scale)
         self.spec = param_spec(action_size, objective_size, use_lstm, use_pixel_change, use_value_replay,
                                use_reward_prediction)
         self.params = FlatParams(self.spec, self._device)
@@ -169,6 +172,14 @@ class UnrealModel(object):
         self.entropy = self.pc_loss = self.vr_loss = self.rp_loss = None
         self._b1 = None
         self._shadow = None
+
+    def bind_frame_scale(self, scale):
+        """Adopt the byte scale of the environment whose ring this network reads (raises if the caller fixed another)."""
+        scale = float(scale)
+        if self._frame_scale_given and abs(self.frame_scale - scale) > 1e-12:
+            raise ValueError("UnrealModel(frame_scale=%r) but the environment stores frames at scale %r"
+                             % (self.frame_scale, scale))
+        self.frame_scale = scale
 
     # -- bf16x3 weight shadows (W operand of ops.gemm_split_nt) ---------------------------------------
     def refresh_shadows(self):

@@ -123,14 +123,25 @@ def pixel_change_u8(frames, idx_new, idx_old, denom, out):
     _call("unreal_pixel_change_u8", N, ptr(frames), ptr(idx_new), ptr(idx_old), float(denom), ptr(out))
 
 
-def philox_uniform(seed, stream_id, out):
+def _philox_shape(n, row_len, row_stride, col0):
+    row_len = n if row_len is None else int(row_len)
+    row_stride = row_len if row_stride is None else int(row_stride)
+    if row_len <= 0 or n % row_len or col0 < 0 or col0 + row_len > row_stride:
+        raise ValueError("philox: n=%d row_len=%d row_stride=%d col0=%d" % (n, row_len, row_stride, col0))
+    return row_len, row_stride, int(col0)
+
+
+def philox_uniform(seed, stream_id, out, row_len=None, row_stride=None, col0=0):
+    """out[i] = draw (i // row_len) * row_stride + col0 + i % row_len of stream (seed, stream_id)."""
     _chk(out, "f64")
-    _call("unreal_philox_uniform", int(seed), int(stream_id), out.numel(), ptr(out))
+    rl, rs, c0 = _philox_shape(out.numel(), row_len, row_stride, col0)
+    _call("unreal_philox_uniform", int(seed), int(stream_id), out.numel(), rl, rs, c0, ptr(out))
 
 
-def philox_randint(seed, stream_id, high, out):
+def philox_randint(seed, stream_id, high, out, row_len=None, row_stride=None, col0=0):
     _chk(out, "i32")
-    _call("unreal_philox_randint", int(seed), int(stream_id), out.numel(), int(high), ptr(out))
+    rl, rs, c0 = _philox_shape(out.numel(), row_len, row_stride, col0)
+    _call("unreal_philox_randint", int(seed), int(stream_id), out.numel(), rl, rs, c0, int(high), ptr(out))
 
 
 # ---- replay --------------------------------------------------------------------------------------

@@ -4,8 +4,17 @@ The reference has no collective (threads race on one variable set: main.py:455,
 rmsprop_applier.py:86-93).  Here rank r owns actors [r*B, (r+1)*B) with their env state, LSTM state
 and replay ring entirely in its own HBM; the only cross-GPU step is a SUM all-reduce of the flat
 gradient buffer (each rank's contribution is already scaled by 1/(B*world), so the sum is the mean
-over all actors).  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
+over all actors).  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests and by
+the rehearsal of several ranks on ONE device (RCCL refuses two ranks on the same GPU).
+
+`launch_ranks` is the self-launcher behind `python bench.py --gpus N`: it starts N fresh child
+processes with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set (never re-executing a process that has touched
+the GPU), relays rank 0's stdout and returns the worst exit code."""
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -15,17 +24,49 @@ def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend=None):
+def device_index(local_rank=None):
+    """GPU of this rank: LOCAL_RANK, or UNREAL_FORCE_DEVICE when several ranks rehearse on one device."""
+    if local_rank is None:
+        local_rank = dist_env()[1]
+    return int(os.environ.get("UNREAL_FORCE_DEVICE", local_rank))
+
+
+def default_backend():
+    """nccl (= RCCL) for one rank per GPU; gloo when there is no GPU or ranks share a device."""
+    forced = os.environ.get("UNREAL_DIST_BACKEND")
+    if forced:
+        return forced
+    if not torch.cuda.is_available():
+        return "gloo"
+    if "UNREAL_FORCE_DEVICE" in os.environ and dist_env()[2] > 1:
+        return "gloo"            # RCCL: "Duplicate GPU detected" for two ranks on one device
+    return "nccl"
+
+
+def init_distributed(backend=None, force=False):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for a single process unless
+    `force`, which builds a 1-rank group: that is how the RCCL path is exercised on a one-GPU box)."""
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = os.environ.get("UNREAL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = default_backend()
+        kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dev = device_index(local_rank)
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized()
 
 
 def actor_range(rank, per_rank_actors):
@@ -33,26 +74,94 @@ def actor_range(rank, per_rank_actors):
 
 
 def all_reduce_sum(flat):
-    """In-place SUM all-reduce of one flat buffer (no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place SUM all-reduce of one flat buffer (no-op without a process group)."""
+    if _active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 
+def all_true(flag, device):
+    """True iff `flag` holds on EVERY rank (MIN all-reduce): the replay-full phase switch must be taken by all ranks
+    in the same process() call, or their gradient all-reduces would pair up off by one call and hang."""
+    if not (_active() and dist.get_world_size() > 1):
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(values, device):
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [float(x) for x in t.tolist()]
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def shutdown():
+    if _active():
+        dist.destroy_process_group()
+
+
+# ---- self-launcher ----------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(script, argv, world, extra_env=None, poll_s=0.5, grace_s=20.0):
+    """Start `world` children `python script argv...`, one per rank, from a parent that has not touched the GPU.
+    Rank 0's stdout is relayed to this process's stdout, the other ranks' stdout goes to stderr (so the caller
+    still sees exactly one JSON line).  If a rank dies, the survivors get `grace_s` seconds, then are terminated by
+    PID (they would otherwise wait in a collective forever).  Returns the worst exit code."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        if extra_env:
+            env.update(extra_env)
+        out = None if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+    first_fail = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if first_fail is None and any(c not in (None, 0) for c in codes):
+            first_fail = time.time()
+        if first_fail is not None and time.time() - first_fail > grace_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(poll_s)
+    codes = [p.wait() for p in procs]
+    worst = 0
+    for c in codes:
+        if c != 0:
+            worst = c if c > 0 else 128 - c
+            break
+    return worst

@@ -38,22 +38,27 @@ def log_uniform(lo, hi, rate):
 
 
 class PhiloxDraws(object):
-    """Device draws; every call consumes a fresh Philox stream id (rank-disjoint)."""
+    """Device draws; every call consumes a fresh Philox stream id.  Every rank makes the same sequence of calls and
+    reads its own actors' columns [rank*B, (rank+1)*B) of the call's global draw, so the trajectories of a job do not
+    depend on how many GPUs its actors are sharded over (batch=None: a plain stream, single process)."""
 
-    def __init__(self, seed, rank=0):
+    def __init__(self, seed, rank=0, batch=None, world_size=1):
         self.seed = int(seed)
-        self.counter = (int(rank) << 40) + 1
+        self.counter = 1
+        self.batch = None if batch is None else int(batch)
+        self.stride = None if batch is None else int(batch) * int(world_size)
+        self.col0 = 0 if batch is None else int(rank) * int(batch)
 
     def _next(self):
         self.counter += 1
         return self.counter
 
     def uniform(self, out):
-        ops.philox_uniform(self.seed, self._next(), out)
+        ops.philox_uniform(self.seed, self._next(), out, self.batch, self.stride, self.col0)
         return out
 
     def randint(self, high, out):
-        ops.philox_randint(self.seed, self._next(), high, out)
+        ops.philox_randint(self.seed, self._next(), high, out, self.batch, self.stride, self.col0)
         return out
 
 
@@ -98,7 +103,7 @@ class Trainer(object):
                                                            global_network.get_vars(), thread_index)
         self.sync = self.local_network.sync_from(global_network)
         self.initial_learning_rate = initial_learning_rate
-        self.draws = draws if draws is not None else PhiloxDraws(seed, rank)
+        self.draws = draws if draws is not None else PhiloxDraws(seed, self.rank, self.B, self.world_size)
         self.local_t = 0
         self.episode_reward = 0
         self.prev_local_t = -1
@@ -125,6 +130,7 @@ class Trainer(object):
                                                   objective_size=self.objective_size,
                                                   reward_divisor=termination_time if indoor else 1.0)
         self.ring = self.environment.ring
+        self.local_network.bind_frame_scale(self.environment.frame_scale)
         self.experience = Experience(self.experience_history_size, ring=self.ring)
         lstm = self.use_lstm
         aux = self.use_pixel_change or self.use_value_replay
@@ -202,9 +208,14 @@ class Trainer(object):
             self.lstm_c.copy_(ws.c[:B * 256])
             self.lstm_h.copy_(ws.h[:B * 256])
         self._fill_calls += 1
-        if self._fill_calls >= self.experience_history_size and self.experience.is_full():
-            self.environment.reset()           # trainer.py:203-205
-            self._full = True
+        if self._fill_calls >= self.experience_history_size:
+            full = self.experience.is_full()
+            if self.world_size > 1:            # every rank leaves the fill phase in the SAME call (the learn phase
+                from .. import parallel        # issues one gradient all-reduce per call: ranks must stay paired)
+                full = parallel.all_true(full, self.device)
+            if full:
+                self.environment.reset()       # trainer.py:203-205
+                self._full = True
 
     def _rollout(self):
         """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
