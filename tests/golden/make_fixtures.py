@@ -9,6 +9,8 @@ Reference functions exercised (file:line under /root/reference):
   environment/maze_environment.py:30-128   MazeEnvironment (_setup, reset, _move, process)
   environment/environment.py:88-102        Environment._calc_pixel_change / _subsample
   train/experience.py:10-153               ExperienceFrame, Experience
+  train/experience_lab_ver.py:10-152       upstream replay (reward clip, zero / non-zero buckets, global np.random)
+  environment/environment.py:88-102        _calc_pixel_change on uint8/255 float32 frames (the Lab wrapper's frames)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py
 """
@@ -148,6 +150,92 @@ def replay_fixture():
     np.savez_compressed(os.path.join(OUT, "replay_traces.npz"), **out)
 
 
+def lab_replay_fixture():
+    """Upstream replay used for Lab (train/experience_lab_ver.py): rewards clipped to [-1, 1] when the frame is built
+    (:14,18), zero / non-zero reward buckets (:76-80), draws from the GLOBAL numpy RandomState (:102,124,138,141).
+    The draws are logged by wrapping np.random.randint around the calls (the reference itself is untouched)."""
+    import train.experience_lab_ver as LV
+    H, n_add = 64, 400
+    srs = np.random.RandomState(17)
+    raw = srs.choice([-3.0, -1.0, -0.5, 0.0, 0.0, 0.0, 0.0, 0.5, 1.0, 2.5], size=n_add)
+    terms = (srs.random_sample(n_add) < 0.08)
+    terms[100] = terms[101] = True            # successive terminals -> second must be discarded
+    terms[200:206] = False
+    np.random.seed(0xA3C)
+    log = []
+    real_randint = np.random.randint
+
+    def logging_randint(*a, **k):
+        v = real_randint(*a, **k)
+        log.append((a[-1] if a else k.get("high"), int(v)))
+        return v
+
+    exp = LV.Experience(H, None)
+    tops, nzero, nnon, lens = [], [], [], []
+    st_reward, st_last_reward, st_id = [], [], []
+    seq_ids, seq_start, rp_ids, rp_coin, rp_pick, rp_n, sample_at = [], [], [], [], [], [], []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for i in range(n_add):
+            last_r = raw[i - 1] if i else 0.0
+            f = LV.ExperienceFrame({"id": i}, raw[i], i % 6, bool(terms[i]), None, (i + 5) % 6, last_r)
+            before = len(exp._frames) + exp._top_frame_index
+            exp.add_frame(f)
+            if len(exp._frames) + exp._top_frame_index != before:          # the frame was accepted
+                st_reward.append(float(f.reward)); st_last_reward.append(float(f.last_reward)); st_id.append(i)
+            tops.append(exp._top_frame_index)
+            nzero.append(len(exp._zero_reward_indices))
+            nnon.append(len(exp._non_zero_reward_indices))
+            lens.append(len(exp._frames))
+            if exp.is_full() and i % 3 == 0:
+                np.random.randint = logging_randint
+                try:
+                    del log[:]
+                    fr = exp.sample_sequence(21)
+                    seq_start.append(log[0][1])
+                    seq_ids.append([x.state["id"] for x in fr] + [-1] * (21 - len(fr)))
+                    del log[:]
+                    fr = exp.sample_rp_sequence()
+                    rp_coin.append(log[0][1]); rp_n.append(log[1][0]); rp_pick.append(log[1][1])
+                    rp_ids.append([x.state["id"] for x in fr])
+                finally:
+                    np.random.randint = real_randint
+                sample_at.append(i)
+    np.savez_compressed(
+        os.path.join(OUT, "replay_lab_ver.npz"), H=np.array([H]), raw_reward=raw, terminals=terms.astype(np.uint8),
+        top=np.array(tops), n_zero=np.array(nzero), n_nonzero=np.array(nnon), length=np.array(lens),
+        stored_reward=np.array(st_reward), stored_last_reward=np.array(st_last_reward), stored_id=np.array(st_id),
+        seq_ids=np.array(seq_ids), seq_start=np.array(seq_start), rp_ids=np.array(rp_ids), rp_coin=np.array(rp_coin),
+        rp_pick=np.array(rp_pick), rp_n=np.array(rp_n), sample_at=np.array(sample_at),
+        final_zero=np.array(exp._zero_reward_indices), final_nonzero=np.array(exp._non_zero_reward_indices),
+        car_clip=LV.ExperienceFrame({}, 2.5, 1, False, None, 3, -7.0).get_last_action_reward(6))
+
+
+def pixel_change_fixture():
+    """Environment._calc_pixel_change (environment.py:93-99) on frames as the Lab wrapper makes them
+    (lab_environment.py:99-102: uint8 / 255 as float32).  Inputs are regenerated from the seed by the tests; only
+    the outputs (float32 [N,20,20]) and an input checksum are stored."""
+    env = MazeEnvironment()
+    rs = np.random.RandomState(4242)
+    N = 96
+    u8 = rs.randint(0, 256, size=(N, 2, 84, 84, 3)).astype(np.uint8)
+    u8[1, 1] = u8[1, 0]                                   # identical frames -> exact zeros
+    u8[2, 0] = 0; u8[2, 1] = 255                          # maximum change -> exact ones
+    u8[3, 1] = u8[3, 0]; u8[3, 1, 40:44, 40:44, :] ^= 0x80  # one 4x4 block
+    for k in range(4, 20):                                # sparse changes like a moving sprite
+        u8[k, 1] = u8[k, 0]
+        y, x = rs.randint(0, 70, size=2)
+        u8[k, 1, y:y + 12, x:x + 12, :] = rs.randint(0, 256, size=(12, 12, 3))
+    out = np.zeros((N, 20, 20), np.float32)
+    for k in range(N):
+        a = u8[k, 0].astype(np.float32) / 255.0
+        b = u8[k, 1].astype(np.float32) / 255.0
+        pc = env._calc_pixel_change(b, a)
+        assert pc.dtype == np.float32 and pc.shape == (20, 20)
+        out[k] = pc
+    np.savez_compressed(os.path.join(OUT, "pixel_change_u8.npz"), seed=np.array([4242]), n=np.array([N]),
+                        pixel_change=out, checksum=np.array([int(u8.astype(np.uint64).sum())]))
+
+
 def known_answers():
     # RMSProp known-answer arithmetic as written in train/rmsprop_applier_test.py:29-51
     # (the test itself needs TensorFlow; these are the values its assertions compute).
@@ -169,6 +257,8 @@ def known_answers():
 if __name__ == "__main__":
     maze_fixture()
     replay_fixture()
+    lab_replay_fixture()
+    pixel_change_fixture()
     known_answers()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -105,7 +105,8 @@ def test_two_ranks_on_one_device_match_one_process_with_all_actors(tmp_path):
 
 def test_rccl_single_rank_group(tmp_path):
     """backend "nccl" IS RCCL: a 1-rank communicator on the device runs the same all_reduce call on the flat gradient
-    buffer that the N-GPU job issues; the update must equal the run without any process group, bit for bit."""
+    buffer that the N-GPU job issues; the update must equal the run without any process group (the weight-gradient
+    kernels accumulate with float atomics, so two runs agree to summation order, not bit for bit)."""
     codes = _spawn(1, "nccl", str(tmp_path))
     assert codes == [0], codes
     r0 = np.load(tmp_path / "rank0.npz")
@@ -113,7 +114,7 @@ def test_rccl_single_rank_group(tmp_path):
     net, tr = _make_trainer(0, 1, B, torch.device("cuda", 0), None)
     ref, steps = _run(tr, net, 1, B)
     assert list(r0["steps"]) == steps
-    np.testing.assert_array_equal(r0["params"], ref)
+    np.testing.assert_allclose(r0["params"], ref, rtol=2e-5, atol=2e-6)
 
 
 def test_bench_self_launches_its_ranks():

@@ -139,3 +139,233 @@ def test_sampled_sequences_and_rp_triples(trained):
     assert ((s[:, 1] - s[:, 0]) % H1 == 1).all() and ((s[:, 2] - s[:, 1]) % H1 == 1).all()
     r4 = rew[np.arange(B), (s[:, 2] + 1) % H1]                             # reward of the 4th frame (trainer.py:427-434)
     assert (cls == np.where(r4 == 0, 0, np.where(r4 > 0, 1, 2))).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-SHAPE value parity.  The small-shape tests (test_kernels_gpu.py, test_trainer_gpu.py) run the fp kernels at
+# <= 4096 rows; production launches are 81,920 - 86,016 rows (grid-stride tails, split-K slab counts, XCD block order).
+# Here the branches of ONE full-size compute_gradients() are run one at a time and
+#   * the activations of 64 random actors (all their rows) are recomputed by the fp64 CPU oracle from the ring frames
+#     and the current weights: conv2 output, fc, LSTM c / h, pi, V, pixel-control fc, d(loss)/d(deconv), value replay V,
+#     reward-prediction logits;
+#   * the big backward kernels are re-launched on the LIVE full-size operands into fresh buffers and compared with an
+#     fp64 PyTorch evaluation of the same op on the device (test infrastructure: torch.matmul / conv in float64).
+# Tolerances: forward 2e-5 abs + 2e-5 rel (5e-5 after the 20-step LSTM), gradients 2e-4 of the largest element --
+# the bars of the small-shape tests.
+# ---------------------------------------------------------------------------------------------------------------------
+N_ACT = 64
+
+
+def _close(got, ref, atol, rtol, what):
+    got = got.detach().cpu().double().numpy()
+    ref = ref.detach().cpu().double().numpy()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = np.abs(got - ref) - (atol + rtol * np.abs(ref))
+    assert err.max() <= 0, "%s: max |d| = %g (ref %g) over %s" % (what, np.abs(got - ref).max(),
+                                                                  ref.flat[np.argmax(err)], (got.shape,))
+
+
+def _close_grad(got, ref, what, rel=2e-4):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = float(ref.abs().max())
+    assert scale > 0, what
+    assert float((got - ref).abs().max()) <= rel * scale, "%s: max |d| = %g, max |ref| = %g" % (
+        what, float((got - ref).abs().max()), scale)
+
+
+def _p64(net):
+    return {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+
+
+def _actor_rows(ws, ring, net, b, n, A):
+    """Frames (fp64, scaled) and last_action_reward columns of rows t*B + b, t < n, of a path workspace."""
+    rows = torch.arange(n, device=DEV) * B + b
+    idx = ws.frame_idx[rows].long()
+    x = ring.frames.view(-1, 84, 84, 3)[idx].cpu().double() * net.frame_scale
+    lar = ws.xcat.view(-1, ws.xld)[rows, 256:256 + A + 1].cpu().double()
+    return rows, x, lar
+
+
+def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what):
+    """conv2 output, fc, LSTM c / h of actor b's first n rows vs the oracle; returns (rows, features fp64)."""
+    from oracle import model as M
+    A = tr.action_size
+    rows, x, lar = _actor_rows(ws, tr.ring, net, b, n, A)
+    _, h2 = M.encoder(x, p64)
+    f = M.fc1(h2, p64)
+    _close(ws.f2.view(-1, 2592)[rows], h2.reshape(n, 2592), 2e-5, 2e-5, what + " conv2")
+    _close(ws.xcat.view(-1, ws.xld)[rows, :256], f, 2e-5, 2e-5, what + " fc")
+    W, bias = p64["lstm_kernel"], p64["lstm_bias"]
+    c, h = c0, h0
+    cs, hs = [], []
+    for t in range(n):
+        g = torch.cat([f[t], lar[t], h]) @ W + bias
+        i, j, fg, o = g[0:256], g[256:512], g[512:768], g[768:1024]
+        c = c * torch.sigmoid(fg + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+        h = torch.tanh(c) * torch.sigmoid(o)
+        cs.append(c); hs.append(h)
+    cs, hs = torch.stack(cs), torch.stack(hs)
+    _close(ws.c.view(-1, 256)[rows], cs, 5e-5, 5e-5, what + " lstm c")
+    _close(ws.h.view(-1, 256)[rows], hs, 5e-5, 5e-5, what + " lstm h")
+    return rows, hs
+
+
+@pytest.fixture(scope="module")
+def branches(trained):
+    """Roll out once more at full size and leave the BASE branch's activations / gradient temporaries in place."""
+    flags, net, tr, _, _ = trained
+    net.refresh_shadows()
+    tr._rollout()
+    net.grads.flat.zero_()
+    tr.losses.zero_()
+    tr._train_base()
+    torch.cuda.synchronize()
+    rs = np.random.RandomState(77)
+    return flags, net, tr, rs.choice(B, size=N_ACT, replace=False), _p64(net)
+
+
+def test_fullshape_base_rows_match_oracle(branches):
+    from oracle import model as M
+    flags, net, tr, actors, p64 = branches
+    ws, A = tr.base_ws, tr.action_size
+    n_steps = tr.n_steps.cpu().numpy()
+    c0 = ws.c0.view(B, 256).cpu().double()
+    h0 = ws.h0.view(B, 256).cpu().double()
+    for b in actors:
+        n = int(n_steps[b])
+        rows, feat = _check_trunk(net, tr, ws, int(b), n, c0[b], h0[b], p64, "base actor %d" % b)
+        pi, v = M.policy_value(feat, p64)
+        _close(tr.pi.view(-1, A)[rows], pi, 5e-5, 5e-5, "pi")
+        _close(tr.v[rows], v, 5e-5, 5e-5, "V")
+
+
+def test_fullshape_backward_kernels_match_fp64(branches):
+    """encoder_bwd (all three phases), the fc1 wgrad (split-K TN) and the fc1 dgrad (NT + ReLU mask) re-launched with
+    the production arguments on the live 81,920-row operands, against fp64 on the device."""
+    import torch.nn.functional as F
+    from unreal_amd import ops
+    from unreal_amd.model.model import _splitk
+    flags, net, tr, actors, p64 = branches
+    ws, gws, ring, p = tr.base_ws, tr.gws, tr.ring, net.p
+    rows = T * B
+    f2 = ws.f2[:rows * 2592].view(rows, 2592)
+    d_fc = gws.d_fc[:rows * 256].view(rows, 256)
+    d_f2 = gws.d_f2[:rows * 2592].view(rows, 2592)
+    z = lambda n: torch.zeros(n, device=DEV)
+    # fc1 weight + bias gradient
+    gW, gb = z(2592 * 256), z(256)
+    ops.gemm_split_tn(2592, 256, rows, ws.f2, 2592, gws.d_fc, 256, gW, 256, splitk=_splitk(2592, 256, rows), colsum=gb)
+    ref = torch.zeros(2592, 256, dtype=torch.float64, device=DEV)
+    for r0 in range(0, rows, 8192):
+        ref += f2[r0:r0 + 8192].double().t() @ d_fc[r0:r0 + 8192].double()
+    _close_grad(gW.view(2592, 256), ref, "fc1 wgrad at %d rows" % rows)
+    _close_grad(gb, d_fc.double().sum(0), "fc1 bias grad")
+    # fc1 input gradient with the conv2 ReLU mask (d_f2 as the trainer left it)
+    Wd = net.params.shaped("W_base_fc1").double()
+    worst, scale = 0.0, 0.0
+    for r0 in range(0, rows, 8192):
+        want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
+        worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
+        scale = max(scale, float(want.abs().max()))
+    assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad", worst, scale)
+    # conv encoder backward
+    dW1, db1, dW2, db2 = z(3072), z(16), z(8192), z(32)
+    ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], net.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2, dW1, db1, dW2, db2)
+    W2 = net.params.shaped("W_base_conv2").double()                    # [4,4,16,32] HWIO
+    w2_oihw = W2.permute(3, 2, 0, 1).contiguous()                      # conv weight [32,16,4,4]
+    r_dW2 = torch.zeros(256, 32, dtype=torch.float64, device=DEV)      # rows (c, ky, kx) as F.unfold orders them
+    r_dW1 = torch.zeros(192, 16, dtype=torch.float64, device=DEV)      # rows (cin, ky, kx)
+    r_db1 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    r_db2 = torch.zeros(32, dtype=torch.float64, device=DEV)
+    frames4 = ring.frames.view(-1, 84, 84, 3)
+    CH = 1024
+    for r0 in range(0, rows, CH):
+        n = min(CH, rows - r0)
+        c1 = ws.c1[r0 * 6400:(r0 + n) * 6400].view(n, 20, 20, 16).double().permute(0, 3, 1, 2)      # [n,16,20,20]
+        d2 = d_f2[r0:r0 + n].double().view(n, 9, 9, 32).permute(0, 3, 1, 2).contiguous()           # [n,32,9,9]
+        r_db2 += d2.sum((0, 2, 3))
+        r_dW2 += torch.einsum("nkp,nop->ko", F.unfold(c1, 4, stride=2), d2.reshape(n, 32, 81))
+        d1 = F.conv_transpose2d(d2, w2_oihw, stride=2) * (c1 > 0)                                   # [n,16,20,20]
+        r_db1 += d1.sum((0, 2, 3))
+        x = frames4[ws.frame_idx[r0:r0 + n].long()].double().permute(0, 3, 1, 2) * net.frame_scale  # [n,3,84,84]
+        r_dW1 += torch.einsum("nkp,nop->ko", F.unfold(x, 8, stride=4), d1.reshape(n, 16, 400))
+    r_dW2 = r_dW2.view(16, 4, 4, 32).permute(1, 2, 0, 3).reshape(256, 32)        # -> (ky, kx, c)
+    r_dW1 = r_dW1.view(3, 8, 8, 16).permute(1, 2, 0, 3).reshape(192, 16)         # -> (ky, kx, cin)
+    _close_grad(dW2.view(256, 32), r_dW2, "conv2 wgrad at %d frames" % rows)
+    _close_grad(db2, r_db2, "conv2 bias grad")
+    _close_grad(dW1.view(192, 16), r_dW1, "conv1 wgrad")
+    _close_grad(db1, r_db1, "conv1 bias grad")
+    # and the trainer's own accumulation of the base branch is the same numbers
+    _close_grad(net.g["W_base_conv2"].view(256, 32), r_dW2, "g[W_base_conv2] (base branch)")
+    _close_grad(net.g["W_base_fc1"].view(2592, 256), ref, "g[W_base_fc1] (base branch)")
+
+
+def test_fullshape_pixel_control_rows_match_oracle(branches):
+    import torch.nn.functional as F
+    flags, net, tr, actors, p64 = branches
+    tr._train_pc()
+    torch.cuda.synchronize()
+    ws, gws, A, Ta = tr.aux_ws, tr.gws, tr.action_size, tr.local_t_max
+    mask = tr.seq_mask.view(Ta, B).cpu().numpy()
+    z = torch.zeros(256, dtype=torch.float64)
+    Wv = p64["W_pc_deconv_v"].permute(3, 2, 0, 1)
+    Wa = p64["W_pc_deconv_a"].permute(3, 2, 0, 1)
+    checked = 0
+    for b in actors:
+        n = int(mask[:, b].sum())
+        assert mask[:n, b].all()
+        if n == 0:
+            continue
+        rows, feat = _check_trunk(net, tr, ws, int(b), n, z, z, p64, "pc actor %d" % b)
+        hp = torch.relu(feat @ p64["W_pc_fc1"] + p64["b_pc_fc1"])
+        _close(gws.hp.view(-1, 2592)[rows], hp, 2e-5, 2e-5, "pc fc")
+        h = hp.reshape(n, 9, 9, 32).permute(0, 3, 1, 2)
+        v_pre = F.conv_transpose2d(h, Wv, p64["b_pc_deconv_v"], stride=2).detach().requires_grad_(True)
+        a_pre = F.conv_transpose2d(h, Wa, p64["b_pc_deconv_a"], stride=2).detach().requires_grad_(True)
+        v, a = torch.relu(v_pre), torch.relu(a_pre)
+        q = v + a - a.mean(dim=1, keepdim=True)                                   # [n,A,20,20]
+        act = tr.seq_act[rows].cpu().long()
+        qa = q[torch.arange(n), act]                                              # [n,20,20]
+        pc_R = gws.pc_R.view(-1, 400)[rows].cpu().double().view(n, 20, 20)
+        loss = tr.pixel_change_lambda * 0.5 * ((pc_R - qa) ** 2).sum() * tr.grad_scale
+        loss.backward()
+        want = torch.cat([v_pre.grad, a_pre.grad], 1).permute(0, 2, 3, 1).reshape(n, 400, 1 + A)
+        _close_grad(gws.d_dec.view(-1, 400, 1 + A)[rows], want, "d_dec actor %d" % b)
+        checked += n
+    assert checked > N_ACT * Ta // 2
+    # bootstrap Q-max of the 4096-row launch
+    hpb = tr.boot_hp.view(B, 2592)[torch.as_tensor(actors, device=DEV)].cpu().double()
+    h = hpb.reshape(-1, 9, 9, 32).permute(0, 3, 1, 2)
+    v = torch.relu(F.conv_transpose2d(h, Wv, p64["b_pc_deconv_v"], stride=2))
+    a = torch.relu(F.conv_transpose2d(h, Wa, p64["b_pc_deconv_a"], stride=2))
+    qmax = (v + a - a.mean(dim=1, keepdim=True)).max(dim=1)[0].reshape(-1, 400)
+    _close(tr.boot_qmax.view(B, 400)[torch.as_tensor(actors, device=DEV)], qmax, 2e-5, 2e-5, "bootstrap Q-max")
+
+
+def test_fullshape_value_replay_and_reward_prediction_rows_match_oracle(branches):
+    from oracle import model as M
+    flags, net, tr, actors, p64 = branches
+    tr._train_vr()
+    tr._train_rp()
+    torch.cuda.synchronize()
+    ws, Ta = tr.aux_ws, tr.local_t_max
+    mask = tr.seq_mask.view(Ta, B).cpu().numpy()
+    z = torch.zeros(256, dtype=torch.float64)
+    for b in actors:
+        n = int(mask[:, b].sum())
+        if n == 0:
+            continue
+        rows, feat = _check_trunk(net, tr, ws, int(b), n, z, z, p64, "vr actor %d" % b)
+        _, v = M.policy_value(feat, p64)
+        _close(tr.aux_v[rows], v, 5e-5, 5e-5, "value-replay V")
+    rws = tr.rp_ws
+    frames4 = tr.ring.frames.view(-1, 84, 84, 3)
+    for b in actors:
+        idx = rws.frame_idx[3 * int(b):3 * int(b) + 3].long()
+        x = frames4[idx].cpu().double() * net.frame_scale
+        _, h2 = M.encoder(x, p64)
+        logits = h2.reshape(1, 7776) @ p64["W_rp_fc1"] + p64["b_rp_fc1"]
+        _close(tr.rp_logits.view(B, 3)[int(b)], logits.reshape(3), 2e-5, 2e-5, "rp logits")
+    l = tr.losses.cpu().numpy()
+    assert np.isfinite(l).all() and l[3] > 0 and l[4] > 0 and l[5] > 0

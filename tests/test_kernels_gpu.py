@@ -232,6 +232,79 @@ def test_replay_sampling_matches_oracle(ops):
             assert rc[b] == (0 if r == 0 else (1 if r > 0 else 2))
 
 
+def test_lab_replay_matches_reference_fixture(ops, golden_dir):
+    """Device ring + unreal_replay_sample_seq / unreal_replay_sample_rp(mode=1) vs the trace tests/golden/make_fixtures.py
+    recorded from the reference's upstream replay (train/experience_lab_ver.py:14,18,63-93,100-151): the scripted
+    reward / terminal stream is fed through unreal_hostfed_step (one actor, H = 64, reward clipping on), then at every
+    sample point the reference's own draws (start position; coin and pick, logged around np.random.randint) select
+    frames on the device.  Bit-exact: clipped stored rewards, window, sampled slots, reward class."""
+    g = np.load(os.path.join(golden_dir, "replay_lab_ver.npz"))
+    H = int(g["H"][0]); H1 = H + 1
+    raw, terms = g["raw_reward"], g["terminals"]
+    ring = ops.Ring(1, H, DEV)
+    rs = np.random.RandomState(5)
+    staged = dev(rs.randint(0, 256, size=ops.FRAME_BYTES).astype(np.uint8))
+    ops.hostfed_reset(ring, staged)
+    ring.last_action.fill_(5)                               # the fixture's frame 0 has last_action (0 + 5) % 6
+    sid = list(g["stored_id"])
+    abs_of = {i: j for j, i in enumerate(sid)}              # caller's frame id -> absolute ring index
+    k = 0
+    for i in range(len(raw)):
+        ops.hostfed_step(ring, staged, dev([i % 6], torch.int32), dev([raw[i]], torch.float32),
+                         dev([int(terms[i])], torch.int32), reset_on_terminal=False, clip_reward=True)
+        cnt = int(ring.count.cpu()[0])
+        assert cnt == sid.index(i) + 1 if i in abs_of else cnt == len([x for x in sid if x < i])
+        assert max(0, cnt - H) == g["top"][i] and min(cnt, H) == g["length"][i]
+        if k < len(g["sample_at"]) and i == g["sample_at"][k]:
+            L = 21
+            seq_idx = torch.zeros(L, dtype=torch.int32, device=DEV)
+            seq_len = torch.zeros(1, dtype=torch.int32, device=DEV)
+            ops.replay_sample_seq(ring, L, dev([g["seq_start"][k]], torch.int32), seq_idx, seq_len)
+            want = [x for x in g["seq_ids"][k] if x >= 0]
+            assert int(seq_len.cpu()[0]) == len(want)
+            assert list(seq_idx.cpu().numpy()[:len(want)]) == [abs_of[x] % H1 for x in want]
+            n, pick = int(g["rp_n"][k]), int(g["rp_pick"][k])
+            rp_idx = torch.zeros(3, dtype=torch.int32, device=DEV)
+            rp_cls = torch.zeros(1, dtype=torch.int32, device=DEV)
+            ops.replay_sample_rp(ring, dev([g["rp_coin"][k]], torch.int32), dev([(pick + 0.5) / n], torch.float64), rp_idx,
+                                 rp_cls, mode=1)
+            ids = list(g["rp_ids"][k])
+            assert list(rp_idx.cpu().numpy()) == [abs_of[x] % H1 for x in ids[:3]]
+            r4 = float(np.clip(raw[ids[3]], -1, 1))
+            assert int(rp_cls.cpu()[0]) == (0 if r4 == 0 else (1 if r4 > 0 else 2))
+            k += 1
+    assert k == len(g["sample_at"])
+    rr = ring.r_reward.cpu().numpy(); rlr = ring.r_last_reward.cpu().numpy(); rla = ring.r_last_action.cpu().numpy()
+    cnt = int(ring.count.cpu()[0])
+    assert cnt == len(sid)
+    for j in range(cnt - H, cnt):                           # the live window: rewards as the reference stored them
+        assert rr[j % H1] == g["stored_reward"][j] and rlr[j % H1] == g["stored_last_reward"][j]
+        assert rla[j % H1] == (sid[j] + 5) % 6
+
+
+def test_pixel_change_u8_matches_reference_fixture(ops, golden_dir):
+    """unreal_hostfed_step's pixel change and unreal_pixel_change_u8 vs Environment._calc_pixel_change
+    (environment.py:88-99) evaluated by the reference on 96 uint8/255 float32 frame pairs.  The device sums
+    |a-b| over the 4x4x3 bytes exactly and divides once (fp32): <= 3e-7 from the reference's float32 chain of means."""
+    from tests.test_oracle_golden import lab_u8_pairs
+    g = np.load(os.path.join(golden_dir, "pixel_change_u8.npz"))
+    n = int(g["n"][0])
+    u8 = lab_u8_pairs(int(g["seed"][0]), n)
+    pool = dev(u8.reshape(-1))
+    out = torch.zeros(n * 400, device=DEV)
+    idx_old = dev(np.arange(n) * 2, torch.int32); idx_new = dev(np.arange(n) * 2 + 1, torch.int32)
+    ops.pixel_change_u8(pool, idx_new, idx_old, 48.0 * 255.0, out)
+    close(out.view(n, 20, 20), g["pixel_change"], atol=3e-7, rtol=0, what="pixel_change_u8")
+    # the same through the host-fed step of n actors: old frame = current observation, new frame = staged
+    ring = ops.Ring(n, 4, DEV)
+    ops.hostfed_reset(ring, dev(u8[:, 0].reshape(-1)))
+    z = torch.zeros(n, dtype=torch.int32, device=DEV)
+    ops.hostfed_step(ring, dev(u8[:, 1].reshape(-1)), z, torch.zeros(n, device=DEV), z)
+    pc = ring.r_pc.view(n, 5, 400)[:, 0].reshape(n, 20, 20)
+    close(pc, g["pixel_change"], atol=3e-7, rtol=0, what="hostfed_step pixel change")
+    assert float(pc[1].abs().max()) == 0.0
+
+
 def test_return_scans(ops):
     rs = np.random.RandomState(3)
     B, T = 37, 20

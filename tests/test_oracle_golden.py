@@ -146,3 +146,81 @@ def test_clip_by_global_norm():
     np.testing.assert_allclose(np.sqrt(sum((c ** 2).sum() for c in clipped)), 40.0, rtol=1e-6)
     small, n2 = clip_by_global_norm([np.ones(4, np.float32)], 40.0)
     np.testing.assert_array_equal(small[0], np.ones(4, np.float32))   # scale is exactly 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# upstream (Lab) replay and the generic pixel change: fixtures made by importing the reference's
+# train/experience_lab_ver.py and environment/environment.py (tests/golden/make_fixtures.py)
+# ---------------------------------------------------------------------------------------------------
+def lab_u8_pairs(seed, n):
+    """The uint8 frame pairs of pixel_change_u8.npz, regenerated exactly as make_fixtures.pixel_change_fixture does."""
+    rs = np.random.RandomState(seed)
+    u8 = rs.randint(0, 256, size=(n, 2, 84, 84, 3)).astype(np.uint8)
+    u8[1, 1] = u8[1, 0]
+    u8[2, 0] = 0
+    u8[2, 1] = 255
+    u8[3, 1] = u8[3, 0]
+    u8[3, 1, 40:44, 40:44, :] ^= 0x80
+    for k in range(4, 20):
+        u8[k, 1] = u8[k, 0]
+        y, x = rs.randint(0, 70, size=2)
+        u8[k, 1, y:y + 12, x:x + 12, :] = rs.randint(0, 256, size=(12, 12, 3))
+    return u8
+
+
+def test_lab_replay_scripted_stream(golden_dir):
+    """oracle/experience.py (lab_ver=True + clip_frame) vs train/experience_lab_ver.py:14,18,53-55,76-80,100-151 on
+    a scripted stream: clipped stored rewards, window top / length, zero / non-zero bucket sizes after EVERY add, and
+    the sampled frame ids of sample_sequence(21) / sample_rp_sequence() under the same global-RandomState draws."""
+    from oracle.experience import clip_frame
+    g = _load(golden_dir, "replay_lab_ver.npz")
+    H = int(g["H"][0])
+    raw, terms = g["raw_reward"], g["terminals"]
+    np.random.seed(0xA3C)                                   # the reference draws from the global RandomState
+    exp = OracleExperience(H, np.random, lab_ver=True)
+    k = 0
+    stored = []
+    for i in range(len(raw)):
+        f = clip_frame(Frame({"id": i}, raw[i], i % 6, bool(terms[i]), None, (i + 5) % 6, raw[i - 1] if i else 0.0))
+        if exp.add_frame(f):
+            stored.append((i, f.reward, f.last_reward))
+        assert exp.top == g["top"][i] and len(exp) == g["length"][i]
+        assert len(exp.bucket(False)) == g["n_zero"][i]            # lab_ver: bucket(False) = zero rewards
+        assert len(exp.bucket(True)) == g["n_nonzero"][i]
+        if k < len(g["sample_at"]) and i == g["sample_at"][k]:
+            fr = exp.sample_sequence(21)
+            assert [x.state["id"] for x in fr] + [-1] * (21 - len(fr)) == list(g["seq_ids"][k])
+            fr = exp.sample_rp_sequence()
+            assert [x.state["id"] for x in fr] == list(g["rp_ids"][k])
+            k += 1
+    assert k == len(g["sample_at"]) > 50
+    assert [s[0] for s in stored] == list(g["stored_id"]) and 101 not in g["stored_id"]    # successive terminals dropped
+    assert len(raw) - 10 < len(stored) < len(raw)
+    np.testing.assert_array_equal([s[1] for s in stored], g["stored_reward"])
+    np.testing.assert_array_equal([s[2] for s in stored], g["stored_last_reward"])
+    assert set(np.unique(g["stored_reward"])) == {-1.0, -0.5, 0.0, 0.5, 1.0}                # +-3, 2.5 were clipped
+    assert exp.bucket(False) == list(g["final_zero"]) and exp.bucket(True) == list(g["final_nonzero"])
+    # the logged draws reproduce the picks through the explicit-draw entry points the device test uses
+    np.testing.assert_array_equal(
+        clip_frame(Frame({}, 2.5, 1, False, None, 3, -7.0)).get_last_action_reward(6), g["car_clip"])
+
+
+def test_pixel_change_on_lab_frames(golden_dir):
+    """oracle.maze.calc_pixel_change vs Environment._calc_pixel_change (environment.py:88-99) on 96 uint8/255 float32
+    frame pairs, bit for bit (same numpy expression on the same float32 inputs); and the exact integer form the
+    device uses (sum of |a-b| over 4x4x3 bytes / (48*255)) within 2e-7 of the reference's float32 result."""
+    g = _load(golden_dir, "pixel_change_u8.npz")
+    n = int(g["n"][0])
+    u8 = lab_u8_pairs(int(g["seed"][0]), n)
+    assert int(u8.astype(np.uint64).sum()) == int(g["checksum"][0])
+    for k in range(n):
+        a = u8[k, 0].astype(np.float32) / 255.0
+        b = u8[k, 1].astype(np.float32) / 255.0
+        pc = OM.calc_pixel_change(b, a)
+        assert pc.dtype == np.float32
+        np.testing.assert_array_equal(pc, g["pixel_change"][k])
+    d = np.abs(u8[:, 1, 2:-2, 2:-2, :].astype(np.int64) - u8[:, 0, 2:-2, 2:-2, :].astype(np.int64))
+    sad = d.reshape(n, 20, 4, 20, 4, 3).sum(axis=(2, 4, 5))
+    exact = (sad / (48.0 * 255.0)).astype(np.float32)
+    assert np.abs(exact.astype(np.float64) - g["pixel_change"]).max() <= 2e-7
+    assert (g["pixel_change"][1] == 0).all() and np.abs(g["pixel_change"][2] - 1.0).max() <= 2e-7
