@@ -189,6 +189,10 @@ int unreal_grad_norm(const float* grad, long n, float* scratch /*256 floats*/, f
 int unreal_rmsprop_step(float* var, float* ms, float* mom, const float* grad, long n, float lr, float decay,
                         float momentum, float eps, float clip_norm, const float* norm, void* stream);
 
+/* ---- device-to-device hand-over of 4-byte words (start_lstm_state = base_lstm_state_out, trainer.py:228-230; the
+ * sampled index lists): an ordinary kernel, so the whole path can run under rocprofv3 --pmc ---------------------- */
+int unreal_copy_words(long n, const void* src, void* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,8 @@ def restore(checkpoint_dir, net, applier=None, restore_slots=True):
     if [(n, tuple(s)) for n, s in payload["spec"]] != [(n, tuple(s)) for n, s, _ in net.spec]:
         raise ValueError("checkpoint %s holds a different variable list than this model" % path)
     net.params.flat.copy_(payload["params"])
+    if hasattr(net, "mark_params_changed"):      # derived weight planes must follow the restored parameters
+        net.mark_params_changed()
     if applier is not None:
         applier._create_slots(net.params.flat)
         if restore_slots and payload.get("rms") is not None:

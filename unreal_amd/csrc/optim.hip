@@ -75,9 +75,37 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, f
   }
 }
 
+// dst[i] = src[i] for 4-byte words: the state hand-overs of the hot path (LSTM state, index lists) are launched as an
+// ordinary kernel of this library rather than as hipMemcpyDtoDAsync (whose runtime blit kernel rocprofv3 --pmc
+// cannot instrument: the profiler segfaults inside at::native::copy_device_to_device, profiles/r02_pmc_fault.log).
+__global__ void copy_words_kernel(long n, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int vec) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    const long n4 = n >> 2;
+    for (long k = i; k < n4; k += stride) d4[k] = s4[k];
+    for (long k = (n4 << 2) + i; k < n; k += stride) dst[k] = src[k];
+  } else {
+    for (long k = i; k < n; k += stride) dst[k] = src[k];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int unreal_copy_words(long n, const void* src, void* dst, void* stream) {
+  if (n <= 0 || !src || !dst || ((((uintptr_t)src) | ((uintptr_t)dst)) & 3)) return UNREAL_EINVAL;
+  const int vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+  long work = vec ? (n + 3) / 4 : n;
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_words_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, (const uint32_t*)src,
+                     (uint32_t*)dst, vec);
+  return unreal_launch_status();
+}
 
 // norm_out[0] = ||grad||_2 ; scratch must hold 256 floats
 int unreal_grad_norm(const float* grad, long n, float* scratch, float* norm_out, void* stream) {

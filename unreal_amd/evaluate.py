@@ -49,8 +49,8 @@ class Evaluate(object):
             self.env.process(self.actions, None, self.rewards, self.terminals, reset_on_terminal=True,
                              track_score=True)
             if net._use_lstm:                      # carry the state; zero it where the episode ended
-                ws.c0.copy_(ws.c[:B * 256])
-                ws.h0.copy_(ws.h[:B * 256])
+                ops.copy_(ws.c0, ws.c[:B * 256])
+                ops.copy_(ws.h0, ws.h[:B * 256])
                 ops.reset_state(B, self.terminals, ws.c0, ws.h0)
             term = self.terminals.cpu().numpy()
             score = ring.score_out.cpu().numpy()

@@ -172,6 +172,7 @@ class UnrealModel(object):
         self.entropy = self.pc_loss = self.vr_loss = self.rp_loss = None
         self._b1 = None
         self._shadow = None
+        self._shadow_stale = True
 
     def bind_frame_scale(self, scale):
         """Adopt the byte scale of the environment whose ring this network reads (raises if the caller fixed another)."""
@@ -182,10 +183,15 @@ class UnrealModel(object):
         self.frame_scale = scale
 
     # -- bf16x3 weight shadows (W operand of ops.gemm_split_nt) ---------------------------------------
-    def refresh_shadows(self):
+    def refresh_shadows(self, only_if_stale=False):
         """Re-split the dense-layer weights into the bf16x3 planes the split-operand GEMM multiplies by (forward:
         transposed, dgrad: natural layout).  Cheap (a few MB); called at the start of every Trainer.process /
-        Evaluate.process / batch-1 runner, i.e. after any optimiser step, load or restore."""
+        Evaluate.process / batch-1 runner, i.e. after any optimiser step, load or restore.  `only_if_stale`: skip
+        when no load / sync / optimiser step was announced (mark_params_changed) since the last split -- the replay
+        fill makes 2000 policy steps on frozen weights."""
+        if only_if_stale and self._shadow is not None and not self._shadow_stale:
+            return
+        self._shadow_stale = False
         if self._shadow is None:
             p, A = self.p, self._action_size
             K_x = self.K_x
@@ -227,8 +233,12 @@ class UnrealModel(object):
                 v = rs.uniform(-d, d, size=shape)
             self.p[name].copy_(torch.as_tensor(v.reshape(-1), dtype=torch.float32))
 
+    def mark_params_changed(self):
+        self._shadow_stale = True
+
     def load_named(self, named):
         """Load {name: array} (TF layouts), e.g. parameters exported by another implementation."""
+        self._shadow_stale = True
         for k, v in named.items():
             self.p[k].copy_(torch.as_tensor(np.asarray(v, dtype=np.float32).reshape(-1)))
 
@@ -245,6 +255,7 @@ class UnrealModel(object):
         """global -> local copy (model.py:737-749).  One parameter copy per GPU: nothing to do."""
         if src_network is not self:
             self.params.flat.copy_(src_network.params.flat)
+            self._shadow_stale = True
         return None
 
     def prepare_loss(self):

@@ -439,6 +439,18 @@ def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba):
           ptr(dWa), ptr(dba))
 
 
+def copy_(dst, src):
+    """dst[:] = src for device tensors of one 4-byte dtype (f32 / i32), as a kernel of this library."""
+    if dst.dtype != src.dtype or dst.dtype not in (torch.float32, torch.int32):
+        raise ValueError("copy_: %s <- %s" % (dst.dtype, src.dtype))
+    if not (dst.is_cuda and src.is_cuda and dst.is_contiguous() and src.is_contiguous()):
+        raise ValueError("copy_ needs contiguous device tensors (no CPU fallback)")
+    if dst.numel() != src.numel():
+        raise ValueError("copy_: %d <- %d elements" % (dst.numel(), src.numel()))
+    _call("unreal_copy_words", dst.numel(), ptr(src), ptr(dst))
+    return dst
+
+
 # ---- optimiser -----------------------------------------------------------------------------------
 def grad_norm(grad, scratch, norm_out):
     _chk(grad, "f32"); _chk(scratch, "f32", 256); _chk(norm_out, "f32", 1)

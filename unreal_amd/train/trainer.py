@@ -196,17 +196,18 @@ class Trainer(object):
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
         B, ws = self.B, self.base_ws
-        self.local_network.refresh_shadows()
+        # weights are frozen while the replay fills: split them on the first call (or after an announced load)
+        self.local_network.refresh_shadows(only_if_stale=self._fill_calls > 0)
         if self.use_lstm:
-            ws.c0.copy_(self.lstm_c)
-            ws.h0.copy_(self.lstm_h)
+            ops.copy_(ws.c0, self.lstm_c)
+            ops.copy_(ws.h0, self.lstm_h)
         self.draws.uniform(self.u_act[:B])
         self._policy_step(ws, 0, self.u_act[:B], self.actions[:B], self.pi[:B * self.action_size], self.v[:B])
         self.environment.process(self.actions[:B], None, self.rewards[:B], self.terminals[:B],
                                  reset_on_terminal=True, track_score=False)
         if self.use_lstm:                      # state advances; NOT reset on terminal here (:201-202)
-            self.lstm_c.copy_(ws.c[:B * 256])
-            self.lstm_h.copy_(ws.h[:B * 256])
+            ops.copy_(self.lstm_c, ws.c[:B * 256])
+            ops.copy_(self.lstm_h, ws.h[:B * 256])
         self._fill_calls += 1
         if self._fill_calls >= self.experience_history_size:
             full = self.experience.is_full()
@@ -221,8 +222,8 @@ class Trainer(object):
         """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
         B, T, A, ws, net = self.B, self.n_step_TD, self.action_size, self.base_ws, self.local_network
         if self.use_lstm:
-            ws.c0.copy_(self.lstm_c)           # start_lstm_state
-            ws.h0.copy_(self.lstm_h)
+            ops.copy_(ws.c0, self.lstm_c)           # start_lstm_state
+            ops.copy_(ws.h0, self.lstm_h)
         self.active.fill_(1)
         self.n_steps.zero_()
         self.terminal_end.zero_()
@@ -235,13 +236,13 @@ class Trainer(object):
             ops.rollout_advance(B, self.terminals[s], self.active, self.active_log[s], self.n_steps,
                                 self.terminal_end)
         if self.use_lstm:
-            self.lstm_c.copy_(ws.c[(T - 1) * B * 256:T * B * 256])
-            self.lstm_h.copy_(ws.h[(T - 1) * B * 256:T * B * 256])
+            ops.copy_(self.lstm_c, ws.c[(T - 1) * B * 256:T * B * 256])
+            ops.copy_(self.lstm_h, ws.h[(T - 1) * B * 256:T * B * 256])
         # bootstrap R = V(s_T) for actors still running; LSTM state NOT advanced (model.py:687-704)
         bw = self.boot_ws
         if self.use_lstm:
-            bw.c0.copy_(self.lstm_c)
-            bw.h0.copy_(self.lstm_h)
+            ops.copy_(bw.c0, self.lstm_c)
+            ops.copy_(bw.h0, self.lstm_h)
         self.ring.cur_idx(out=bw.frame_idx[:B])
         feat, ld = net.trunk_forward(self.ring, bw, 1, B, lar_from_ring=False, save_c1=False,
                                      clip_lar=self.rp_mode == 1,   # frame.get_action_reward(): stored (clipped) reward
@@ -283,7 +284,7 @@ class Trainer(object):
     def _aux_forward(self):
         B, Ta, net, ws = self.B, self.local_t_max, self.local_network, self.aux_ws
         rows = Ta * B
-        ws.frame_idx[:rows].copy_(self.seq_idx[:rows])
+        ops.copy_(ws.frame_idx[:rows], self.seq_idx[:rows])
         if self.use_lstm:
             ws.c0.zero_()
             ws.h0.zero_()
@@ -380,6 +381,7 @@ class Trainer(object):
         if self.grad_sync is not None:
             self.grad_sync(net.grads.flat)               # RCCL all-reduce (sum of per-rank means / world)
         self.last_grad_norm = self.grad_applier.step(net.params.flat, net.grads.flat, lr)
+        net.mark_params_changed()
         ops.rollout_stats(self.B, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
         if not sync_stats:                               # stats keep accumulating on the device
             return None, None
