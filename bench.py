@@ -59,7 +59,7 @@ def build_trainer(args, rank, world, device):
                  flags.pixel_change_lambda, flags.entropy_beta, flags.local_t_max, flags.n_step_TD, flags.gamma,
                  flags.gamma_pc, args.history, flags.max_time_step, device, batch_size=args.actors,
                  world_size=world, rank=rank, seed=0xA3C,
-                 grad_sync=parallel.all_reduce_sum if world > 1 else None)
+                 grad_sync=parallel.all_reduce_sum if world > 1 else None, groups=getattr(args, "groups", 1))
     tr.prepare()
     return flags, net, tr
 
@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--actors", type=int, default=4096, help="actors per GPU (BASELINE.json configs[1])")
     ap.add_argument("--history", type=int, default=2000, help="experience_history_size per actor")
+    ap.add_argument("--groups", type=int, default=1, help="sequential updates per process() call (actors are dealt into "
+                    "this many groups; 1 = one update from all actors, the headline configuration)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-threads", type=int, default=8, help="parallel_size of the reference (options.py:37)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,6 +181,7 @@ def main():
         "config": {"workload": "maze_environment full UNREAL (PC+RP+VR), %d batched actors per MI355X, "
                                "n_step_TD=%d, replay history %d/actor (uint8 HBM ring)" % (args.actors, T, args.history),
                    "actors_per_gpu": args.actors, "global_actors": args.actors * world,
+                   "updates_per_call": args.groups,
                    "env_steps_per_call": tot_steps / args.steps, "parallelism": "actors sharded x%d, flat-gradient "
                    "all-reduce (%s)" % (world, backend) if world > 1 else "single GPU", "replay_fill_s": t_fill,
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},

@@ -192,6 +192,8 @@ int unreal_rmsprop_step(float* var, float* ms, float* mom, const float* grad, lo
 /* ---- device-to-device hand-over of 4-byte words (start_lstm_state = base_lstm_state_out, trainer.py:228-230; the
  * sampled index lists): an ordinary kernel, so the whole path can run under rocprofv3 --pmc ---------------------- */
 int unreal_copy_words(long n, const void* src, void* dst, void* stream);
+/* y += alpha * x: the per-call mean of the loss scalars over the G sequential updates of a grouped process() */
+int unreal_axpy_f32(long n, float alpha, const float* x, float* y, void* stream);
 
 #ifdef __cplusplus
 }

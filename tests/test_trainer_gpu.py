@@ -41,7 +41,7 @@ def _cfg(use_lstm, aux, H, T):
                 initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
 
 
-def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=1.0, env_name=""):
+def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=None, env_name="", groups=1):
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
     from unreal_amd.train.rmsprop_applier import RMSPropApplier
@@ -59,7 +59,7 @@ def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=1.0, env_n
                  cfg["use_value_replay"], cfg["use_reward_prediction"], cfg["pixel_change_lambda"],
                  cfg["entropy_beta"], cfg["local_t_max"], cfg["n_step_TD"], cfg["gamma"], cfg["gamma_pc"],
                  cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws,
-                 simulator=simulator)
+                 simulator=simulator, groups=groups)
     tr.prepare()
     return net, applier, tr, draws
 
@@ -182,6 +182,58 @@ def test_process_matches_oracle(use_lstm, aux):
             assert np.abs(got - want).max() <= 2e-6 + 1e-5 * np.abs(want).max(), (it, name)
         global_t += steps_dev
     assert all(len(e.seq_starts) == 0 and len(e.rp_u) == 0 for e in edraws)
+
+
+def test_grouped_process_is_the_reference_algorithm_actor_after_actor():
+    """groups = B: one process() call = B sequential single-actor passes, each with its own clip + RMSProp step on the
+    weights the previous actor left -- the reference's algorithm (trainer.py:438-636) executed thread after thread
+    (oracle: process_async in actor order; hogwild order = call order).  Checked after every call: step counts /
+    actions exact, parameters <= 2e-6 + 2e-5 rel (3 chained updates per call)."""
+    B, H, T = 3, 40, 20
+    cfg = _cfg(True, True, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    net, applier, tr, draws = _build(cfg, B, seed=13, groups=B)
+    assert tr.Bg == 1 and tr.grad_scale == 1.0
+    params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
+    edraws = [ExplicitDraws() for _ in range(B)]
+    orc = OracleTrainer(cfg, n_actors=B, draws=edraws, dtype=torch.float64, params=params)
+    while not tr._full:
+        assert tr.process(None, 0) == (0, None)
+    assert len(draws.log) == H * B                       # one draw call per group and fill step
+    for k, u in enumerate(draws.log):
+        edraws[k % B].action_u.append(float(u[0]))
+    orc.fill()
+    np.testing.assert_array_equal(tr.full_ring.count.cpu().numpy(), [a.exp.count for a in orc.actors])
+    global_t = 0
+    for it in range(3):
+        if it == 1:
+            tr._select_group(0)
+            _teleport(tr, orc, 0, 5, 0)                  # actor 0 finishes an episode inside this call
+        draws.log.clear()
+        steps_dev, score_dev = tr.process(None, global_t)
+        assert len(draws.log) == 5 * B
+        steps_o, scores = 0, []
+        for b in range(B):
+            lg = draws.log[5 * b:5 * b + 5]
+            edraws[b].action_u = [float(x) for x in lg[0]]
+            edraws[b].seq_starts = [int(lg[1][0]), int(lg[2][0])]
+            edraws[b].rp_coin, edraws[b].rp_u = [int(lg[3][0])], [float(lg[4][0])]
+            d, sc, losses = orc.process_async(b, global_t + b * T)
+            steps_o += d
+            if sc is not None:
+                scores.append(sc)
+            edraws[b].action_u = []                      # a terminal leaves unused uniforms behind
+        assert steps_dev == steps_o
+        assert (score_dev is None) == (not scores)
+        if scores:
+            assert abs(score_dev - np.mean(scores)) < 1e-6 and it == 1
+        for name, ref in orc.params.items():
+            got = net.p[name].cpu().double().numpy()
+            want = ref.numpy().reshape(-1)
+            assert np.abs(got - want).max() <= 2e-6 + 2e-5 * np.abs(want).max(), (it, name)
+        global_t += steps_dev
+    # the last group's losses are the last actor's; the published ones are the mean over the call's updates
+    assert np.isfinite(tr.last_losses["total_loss"])
 
 
 def test_batch1_runners_match_oracle():

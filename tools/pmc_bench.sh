@@ -18,3 +18,8 @@ run() {   # name, counters...
 ARGS=("$@")
 run fetch FETCH_SIZE && run write WRITE_SIZE && run mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE && \
 run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
+rc=$?
+# raw per-dispatch CSVs are tens of MB per pass: keep the per-kernel summary only
+STEPS=2; for ((i=0;i<${#ARGS[@]};i++)); do [ "${ARGS[$i]}" = "--steps" ] && STEPS=${ARGS[$((i+1))]}; done
+python3 "$ROOT/tools/pmc_insitu.py" "$OUT" --steps "$STEPS" > "$OUT/pmc_bench.json" && rm -rf "$OUT"/fetch "$OUT"/write "$OUT"/mfma "$OUT"/waves
+exit $rc

@@ -92,9 +92,22 @@ __global__ void copy_words_kernel(long n, const uint32_t* __restrict__ src, uint
   }
 }
 
+__global__ void axpy_kernel(long n, float alpha, const float* __restrict__ x, float* __restrict__ y) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += alpha * x[i];
+}
+
 }  // namespace
 
 extern "C" {
+
+int unreal_axpy_f32(long n, float alpha, const float* x, float* y, void* stream) {
+  if (n <= 0 || !x || !y) return UNREAL_EINVAL;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, alpha, x, y);
+  return unreal_launch_status();
+}
 
 int unreal_copy_words(long n, const void* src, void* dst, void* stream) {
   if (n <= 0 || !src || !dst || ((((uintptr_t)src) | ((uintptr_t)dst)) & 3)) return UNREAL_EINVAL;

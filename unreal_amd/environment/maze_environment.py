@@ -20,6 +20,12 @@ class BatchedMazeEnvironment(object):
         self.ring = ops.Ring(batch, history_size, torch.device(device))
         self.reset()
 
+    def view(self, b0, b1):
+        """The environments [b0, b1) as a batched environment of their own (shares the ring memory)."""
+        v = object.__new__(BatchedMazeEnvironment)
+        v.B, v.ring = b1 - b0, ops.ring_view(self.ring, b0, b1)
+        return v
+
     @staticmethod
     def get_action_size():
         return 4

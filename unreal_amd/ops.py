@@ -97,6 +97,23 @@ class Ring(object):
         return out
 
 
+def ring_view(ring, b0, b1):
+    """The actors [b0, b1) of a ring as a Ring of their own (no copy: frame indices are relative to the view)."""
+    v = object.__new__(Ring)
+    v.B, v.H, v.H1, v.objective_size = b1 - b0, ring.H, ring.H1, ring.objective_size
+    H1 = ring.H1
+    v.frames = ring.frames[b0 * H1 * FRAME_BYTES:b1 * H1 * FRAME_BYTES]
+    for name in ("r_reward", "r_action", "r_terminal", "r_last_action", "r_last_reward"):
+        setattr(v, name, getattr(ring, name)[b0 * H1:b1 * H1])
+    v.r_pc = ring.r_pc[b0 * H1 * PC_CELLS:b1 * H1 * PC_CELLS]
+    obj = ring.objective_size
+    v.r_objective = ring.r_objective[b0 * H1 * obj:b1 * H1 * obj] if obj else None
+    v.pos = ring.pos[2 * b0:2 * b1]
+    for name in ("last_action", "last_reward", "count", "episode_reward", "score_out", "score_valid", "_cur"):
+        setattr(v, name, getattr(ring, name)[b0:b1])
+    return v
+
+
 def maze_reset(ring, mask=None):
     _chk(mask, "i32", ring.B, "mask", optional=True)
     _call("unreal_maze_reset", ring.B, ring.H1, ptr(mask), ptr(ring.pos), ptr(ring.last_action),
@@ -437,6 +454,12 @@ def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba):
     _chk(dWa, "f32", 512 * A); _chk(dba, "f32", A)
     _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(d_dec), ptr(Wv), ptr(Wa), ptr(d_hp), ptr(dWv), ptr(dbv),
           ptr(dWa), ptr(dba))
+
+
+def axpy(alpha, x, y):
+    """y += alpha * x (f32 device vectors)."""
+    _chk(x, "f32"); _chk(y, "f32", x.numel())
+    _call("unreal_axpy_f32", x.numel(), float(alpha), ptr(x), ptr(y))
 
 
 def copy_(dst, src):

@@ -15,6 +15,12 @@ global-norm clip and one RMSProp step.  With B == 1 this is the reference algori
 The rollout's activations are kept in HBM and reused by the backward pass (the reference recomputes
 the same forward with the same synced weights, trainer.py:457,543-570).
 
+`groups=G` restores update density on the batched path: the B actors of the GPU are dealt into G groups of B/G and
+one process() call runs G complete actor-learner passes one after the other -- group g rolls out with the weights
+group g-1 has just updated, its mean gradient is clipped and applied by itself (G RMSProp steps per call).  G = 1 is
+the lock-step learner above; G = B is the reference's algorithm executed actor after actor (zero staleness, the
+order in which hogwild threads would take the lock if there were one).
+
 Per-actor random draws come from a counter RNG (Philox) on the device; `draws` can be replaced to
 replay a recorded stream (parity tests).  TF-only arguments are accepted and ignored.
 """
@@ -69,7 +75,7 @@ class Trainer(object):
                  experience_history_size, max_global_time_step, device, segnet_param_dict=None,
                  image_shape=(84, 84), is_training=True, n_classes=0, random_state=None, termination_time=50.0,
                  segnet_lambda=1.0, dropout=0.0, batch_size=1, world_size=1, rank=0, seed=0xA3C, draws=None,
-                 grad_sync=None, simulator=None):
+                 grad_sync=None, simulator=None, groups=1):
         if env_type != "maze" and simulator is None:
             raise NotImplementedError("env_type=%r needs a host simulator object (simulator=...); only 'maze' runs "
                                       "entirely on the device" % env_type)
@@ -93,9 +99,15 @@ class Trainer(object):
         self.action_size = Environment.get_action_size(env_type, env_name)
         self.objective_size = Environment.get_objective_size(env_type, env_name)
         self.device = torch.device(device if device not in (None, "/gpu:0", "/cpu:0") else "cuda:0")
-        self.B = int(batch_size)
+        self.B = int(batch_size)                     # actors of this rank
+        self.groups = int(groups)                    # sequential updates per process() call
+        if self.groups < 1 or self.B % self.groups:
+            raise ValueError("groups=%d must divide batch_size=%d" % (self.groups, self.B))
+        if self.groups > 1 and env_type != "maze":
+            raise NotImplementedError("groups > 1 needs an environment that steps a sub-range of its actors (maze)")
+        self.Bg = self.B // self.groups              # actors per group = batch of every kernel launch
         self.world_size, self.rank = int(world_size), int(rank)
-        self.grad_scale = 1.0 / float(self.B * self.world_size)
+        self.grad_scale = 1.0 / float(self.Bg * self.world_size)
         self.grad_sync = grad_sync
         self.local_network = global_network          # one parameter copy per GPU (sync_from is a no-op)
         self.grad_applier = grad_applier
@@ -103,6 +115,7 @@ class Trainer(object):
                                                            global_network.get_vars(), thread_index)
         self.sync = self.local_network.sync_from(global_network)
         self.initial_learning_rate = initial_learning_rate
+        self._own_draws = draws is None
         self.draws = draws if draws is not None else PhiloxDraws(seed, self.rank, self.B, self.world_size)
         self.local_t = 0
         self.episode_reward = 0
@@ -129,9 +142,11 @@ class Trainer(object):
                                                   action_size=A, clip_reward=not indoor,
                                                   objective_size=self.objective_size,
                                                   reward_divisor=termination_time if indoor else 1.0)
-        self.ring = self.environment.ring
+        self.full_environment = self.environment
+        self.full_ring = self.ring = self.environment.ring
         self.local_network.bind_frame_scale(self.environment.frame_scale)
-        self.experience = Experience(self.experience_history_size, ring=self.ring)
+        self.experience = Experience(self.experience_history_size, ring=self.full_ring)
+        B = self.Bg                                  # everything below is sized for ONE group
         lstm = self.use_lstm
         aux = self.use_pixel_change or self.use_value_replay
         xld = self.local_network.xld
@@ -144,7 +159,7 @@ class Trainer(object):
         f = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         i = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
         d = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
-        self.lstm_c, self.lstm_h = f(B * 256), f(B * 256)
+        self.full_lstm_c, self.full_lstm_h = f(self.B * 256), f(self.B * 256)
         self.pi, self.v = f(T * B * A), f(T * B)
         self.actions, self.rewards, self.terminals = i(T * B), f(T * B), i(T * B)
         self.active_log, self.active = i(T * B), i(B)
@@ -164,8 +179,24 @@ class Trainer(object):
         if self.use_reward_prediction:
             self.rp_coin, self.rp_u, self.rp_class = i(B), d(B), i(B)
             self.rp_logits, self.rp_dlogits = f(B * 3), f(B * 3)
+        self.loss_sum = f(8)          # losses summed over the groups of one process() call
         self._fill_calls = 0
         self._full = False
+        self._group_views = []
+        for g in range(self.groups):
+            b0, b1 = g * self.Bg, (g + 1) * self.Bg
+            env = self.full_environment if self.groups == 1 else self.full_environment.view(b0, b1)
+            self._group_views.append((env, self.full_lstm_c[b0 * 256:b1 * 256], self.full_lstm_h[b0 * 256:b1 * 256], b0))
+        self._select_group(0)
+
+    def _select_group(self, g):
+        """Point the pipeline at the actors [g*Bg, (g+1)*Bg): environment / ring views, carried LSTM state, draws."""
+        env, c, h, b0 = self._group_views[g]
+        self.group = g
+        self.environment, self.ring, self.lstm_c, self.lstm_h = env, env.ring, c, h
+        if self._own_draws:
+            self.draws.batch = self.Bg
+            self.draws.col0 = self.rank * self.B + b0
 
     def stop(self):
         if self.environment is not None:
@@ -185,7 +216,7 @@ class Trainer(object):
     # ---------------------------------------------------------------------------------------------------
     def _policy_step(self, ws, t, u, actions_out, pi_out, v_out):
         """Forward the current observations of all actors as time row-block t of `ws` and draw actions."""
-        B, A, net = self.B, self.action_size, self.local_network
+        B, A, net = self.Bg, self.action_size, self.local_network
         self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
         net.encode_rows(self.ring, ws, t * B, B, lar_from_ring=False, save_c1=ws.c1 is not None)
         if self.use_lstm:
@@ -195,9 +226,24 @@ class Trainer(object):
 
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
-        B, ws = self.B, self.base_ws
         # weights are frozen while the replay fills: split them on the first call (or after an announced load)
         self.local_network.refresh_shadows(only_if_stale=self._fill_calls > 0)
+        for g in range(self.groups):
+            self._select_group(g)
+            self._fill_group()
+        self._select_group(0)
+        self._fill_calls += 1
+        if self._fill_calls >= self.experience_history_size:
+            full = self.experience.is_full()
+            if self.world_size > 1:            # every rank leaves the fill phase in the SAME call (the learn phase
+                from .. import parallel        # issues one gradient all-reduce per call: ranks must stay paired)
+                full = parallel.all_true(full, self.device)
+            if full:
+                self.full_environment.reset()  # trainer.py:203-205
+                self._full = True
+
+    def _fill_group(self):
+        B, ws = self.Bg, self.base_ws
         if self.use_lstm:
             ops.copy_(ws.c0, self.lstm_c)
             ops.copy_(ws.h0, self.lstm_h)
@@ -208,19 +254,10 @@ class Trainer(object):
         if self.use_lstm:                      # state advances; NOT reset on terminal here (:201-202)
             ops.copy_(self.lstm_c, ws.c[:B * 256])
             ops.copy_(self.lstm_h, ws.h[:B * 256])
-        self._fill_calls += 1
-        if self._fill_calls >= self.experience_history_size:
-            full = self.experience.is_full()
-            if self.world_size > 1:            # every rank leaves the fill phase in the SAME call (the learn phase
-                from .. import parallel        # issues one gradient all-reduce per call: ranks must stay paired)
-                full = parallel.all_true(full, self.device)
-            if full:
-                self.environment.reset()       # trainer.py:203-205
-                self._full = True
 
     def _rollout(self):
         """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
-        B, T, A, ws, net = self.B, self.n_step_TD, self.action_size, self.base_ws, self.local_network
+        B, T, A, ws, net = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network
         if self.use_lstm:
             ops.copy_(ws.c0, self.lstm_c)           # start_lstm_state
             ops.copy_(ws.h0, self.lstm_h)
@@ -254,7 +291,7 @@ class Trainer(object):
                          self.R, self.adv)
 
     def _train_base(self):
-        B, T, A, ws, net, g, p = self.B, self.n_step_TD, self.action_size, self.base_ws, self.local_network, \
+        B, T, A, ws, net, g, p = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network, \
             self.local_network.g, self.local_network.p
         rows = T * B
         ops.base_loss_grad(rows, A, self.pi, A, self.v, self.actions, self.adv, self.R, self.active_log,
@@ -269,7 +306,7 @@ class Trainer(object):
 
     def _sample_sequence(self):
         """experience.sample_sequence(local_t_max+1) for every actor + the bootstrap frame's features."""
-        B, Ta, net = self.B, self.local_t_max, self.local_network
+        B, Ta, net = self.Bg, self.local_t_max, self.local_network
         L = Ta + 1
         self.draws.randint(self.experience_history_size - L - 1, self.seq_start)
         ops.replay_sample_seq(self.ring, L, self.seq_start, self.seq_idx, self.seq_len)
@@ -282,7 +319,7 @@ class Trainer(object):
         return feat, ld
 
     def _aux_forward(self):
-        B, Ta, net, ws = self.B, self.local_t_max, self.local_network, self.aux_ws
+        B, Ta, net, ws = self.Bg, self.local_t_max, self.local_network, self.aux_ws
         rows = Ta * B
         ops.copy_(ws.frame_idx[:rows], self.seq_idx[:rows])
         if self.use_lstm:
@@ -293,7 +330,7 @@ class Trainer(object):
 
     def _train_pc(self):
         """[Pixel change] (trainer.py:339-380, model.py:411-443, 542-557)."""
-        B, Ta, A, net = self.B, self.local_t_max, self.action_size, self.local_network
+        B, Ta, A, net = self.Bg, self.local_t_max, self.action_size, self.local_network
         p, g, gws = net.p, net.g, self.gws
         rows = Ta * B
         feat, ld = self._sample_sequence()
@@ -319,7 +356,7 @@ class Trainer(object):
 
     def _train_vr(self):
         """[Value replay] (trainer.py:383-412, model.py:446-470, 559-566)."""
-        B, Ta, net = self.B, self.local_t_max, self.local_network
+        B, Ta, net = self.Bg, self.local_t_max, self.local_network
         p, g, gws = net.p, net.g, self.gws
         rows = Ta * B
         feat, ld = self._sample_sequence()
@@ -334,7 +371,7 @@ class Trainer(object):
 
     def _train_rp(self):
         """[Reward prediction] (trainer.py:415-436, model.py:473-488, 569-576)."""
-        B, net, ws = self.B, self.local_network, self.rp_ws
+        B, net, ws = self.Bg, self.local_network, self.rp_ws
         p, g, gws = net.p, net.g, self.gws
         self.draws.randint(2, self.rp_coin)
         self.draws.uniform(self.rp_u)
@@ -376,13 +413,23 @@ class Trainer(object):
             self._fill_experience(sess)
             return 0, None
         net = self.local_network
-        lr = self._anneal_learning_rate(global_t)
-        self.compute_gradients()
-        if self.grad_sync is not None:
-            self.grad_sync(net.grads.flat)               # RCCL all-reduce (sum of per-rank means / world)
-        self.last_grad_norm = self.grad_applier.step(net.params.flat, net.grads.flat, lr)
-        net.mark_params_changed()
-        ops.rollout_stats(self.B, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
+        G = self.groups
+        if G > 1:
+            self.loss_sum.zero_()
+        for g in range(G):                               # G complete actor-learner passes, one after the other
+            self._select_group(g)
+            # the reference reads global_t when a worker's process() starts (main.py:114-125)
+            lr = self._anneal_learning_rate(global_t + g * self.Bg * self.n_step_TD * self.world_size)
+            self.compute_gradients()
+            if self.grad_sync is not None:
+                self.grad_sync(net.grads.flat)           # RCCL all-reduce (sum of per-rank means / world)
+            self.last_grad_norm = self.grad_applier.step(net.params.flat, net.grads.flat, lr)
+            net.mark_params_changed()
+            ops.rollout_stats(self.Bg, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
+            if G > 1:
+                ops.axpy(1.0 / G, self.losses, self.loss_sum)
+        if G > 1:
+            self._select_group(0)
         if not sync_stats:                               # stats keep accumulating on the device
             return None, None
         steps, episodes, score_sum = self.read_stats()
@@ -398,7 +445,7 @@ class Trainer(object):
         return steps, episodes, score_sum
 
     def _publish_losses(self):
-        l = self.losses.cpu().numpy()
+        l = (self.loss_sum if self.groups > 1 else self.losses).cpu().numpy()    # groups: mean over the call's updates
         net = self.local_network
         net.policy_loss, net.value_loss, net.entropy = float(l[0]), float(l[1]), float(l[2])
         net.base_loss = net.policy_loss + net.value_loss
