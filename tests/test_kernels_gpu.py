@@ -419,7 +419,7 @@ def test_encoder_fwd(ops, N, mode):
     assert torch.equal(f2, f2b)
 
 
-@pytest.mark.parametrize("N", [1, 6, 131])
+@pytest.mark.parametrize("N", [1, 6, 131, 1100])     # 1100 > 512 workgroups: the grid-stride / prefetch path
 def test_encoder_bwd(ops, N):
     rs = np.random.RandomState(N + 100)
     p = _enc_params(2)

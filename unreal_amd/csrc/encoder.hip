@@ -254,107 +254,153 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
 // accumulators across all frames of the workgroup, flushed once with float atomics), db2, db1.
 //   (1) dW2[(ky,kx,c)][n] += sum_pos c1[2oy+ky][2ox+kx][c] * d2[pos][n]            M=256 N=32 K=81
 //   (2) d1[2a+pa][2b+pb][c] = sum_{da,db,n} d2[a-da][b-db][n] * W2[pa+2da][pb+2db][c][n]
-//       per output parity (pa,pb): M=100 N=16 K=128; masked by c1 > 0 and written in place of c1
+//       per output parity (pa,pb): M=16 channels, N=100 positions, K=128; masked by c1 > 0
 //   (3) dW1[(ky,kx,cin)][c] += scale * sum_pos u8[4oy+ky][4ox+kx][cin] * d1[pos][c]  M=192 N=16 K=400
-// Pipeline per frame: the NEXT frame's uint8 image, c1 and d2 are fetched into registers while phase (3)
-// of the current frame runs and are stored to LDS right after it.
+// ALL three phases run on v_mfma_f32_16x16x32_bf16 with fp32-grade error (the scheme of csrc/gemm_split.hip):
+// every fp32 operand element is split ONCE into three bf16 terms (round-to-nearest, residuals exact: 8+8+8
+// mantissa bits) -- c1 and d2 when the frame is staged into LDS, W2 once per kernel (its fragments stay in
+// registers), d1 in the epilogue of phase (2) -- and each product tile accumulates the six term pairs of weight
+// >= 2^-16 in fp32 (dropped pairs < 2^-24 |ab|); the uint8 pixel is exact in one bf16 term (3 MFMAs per tile).
+// That is 6/16 of the fp32 MFMA's matrix-pipe time for phases (1)-(2).
+//
+// Organisation: one frame per 256-thread workgroup at a time, TWO workgroups per CU (78 KB of LDS each) that run
+// independently -- one's staging / epilogue VALU overlaps the other's MFMAs on the same SIMDs.  LDS per workgroup:
+//   FR  uint8 frame [84][252]
+//   X   c1 planes [3][400 pos][16 ch] bf16; phase (2) overwrites them IN PLACE with the d1 planes (the ReLU mask of
+//       an element is read from its own c1 hi term just before it is overwritten) + one zero row
+//   Z   d2 planes [3][96 pos][32 n] bf16, rows 81..95 zero (K padding of phase (1), "outside" taps of phase (2))
+// Reductions over POSITIONS (phases 1 and 3: the position is the row index of both LDS images) take both operands
+// through ds_read_b64_tr_b16 (a 4-row x 16-column block, transposed in flight; each lane supplies the address of
+// one row, so the strided conv taps need no im2col copy); phase (2) reduces over d2's channel index, contiguous in
+// a row: plain 16-byte fragment reads, and its weight fragments never leave the registers.
+// The NEXT frame's uint8 image, c1 and d2 are fetched into registers behind phase (3) and written to LDS after it.
 // ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+
 constexpr int C1_V = (C1_POS * 4 + 255) / 256;   // f32x4 per thread for one c1 image (7)
 constexpr int D2_V = (C2_POS * 8 + 255) / 256;   // f32x4 per thread for one d2 image (3)
+constexpr int XROW = 32;                         // bytes per conv1 position in a plane (16 bf16)
+constexpr int XPL = C1_POS * XROW;               // 12800
+constexpr int X_BYTES = 3 * XPL + 64;            // + 64 zero bytes
+constexpr int ZROW = 64;                         // bytes per conv2 position in a plane (32 bf16)
+constexpr int ZROWS = 96;
+constexpr int ZPL = ZROWS * ZROW;                // 6144
+constexpr int Z_BYTES = 3 * ZPL;                 // 18432
+constexpr int BWD_LDS = FR_LDS + X_BYTES + Z_BYTES;   // 78080: two workgroups per CU
+static_assert(2 * BWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
-// conv2 dgrad for NT output tiles (16 positions each) of ONE output parity: one weight fragment read
-// (w2t, LDS) feeds all NT tiles.
-template <int NT>
-__device__ __forceinline__ float dgrad_tiles(const float* d2, float* c1, const float* w2t, int par, int mt0, int i,
-                                             int q) {
-  f32x4 acc[NT];
-  int a[NT], b[NT];
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// six term pairs of one product tile, smallest first
+#define SPLIT_MMA(A, B, C)            \
+  do {                                \
+    C = MFMA_BF16(A[2], B[0], C);     \
+    C = MFMA_BF16(A[0], B[2], C);     \
+    C = MFMA_BF16(A[1], B[1], C);     \
+    C = MFMA_BF16(A[1], B[0], C);     \
+    C = MFMA_BF16(A[0], B[1], C);     \
+    C = MFMA_BF16(A[0], B[0], C);     \
+  } while (0)
+
+// 4 fp32 -> three planes of 4 bf16 (round to nearest even; x = pl0 + pl1 + pl2 exactly)
+__device__ __forceinline__ void split4(const f32x4& v, u32x2v (&pl)[3]) {
+  f32x2v x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int m = min((mt0 + t) * 16 + i, 99);
-    a[t] = m / 10;
-    b[t] = m % 10;
-  }
-#pragma unroll
-  for (int dd = 0; dd < 4; ++dd) {
-    const int da = dd >> 1, db = dd & 1;
-    int row[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int y = a[t] - da, x = b[t] - db;
-      row[t] = ((y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS) * D2_LD + 4 * q;
-    }
-#pragma unroll
-    for (int cch = 0; cch < 2; ++cch) {
-      f32x4 av[NT];
-      const f32x4 bw = *reinterpret_cast<const f32x4*>(w2t + ((((par * 4 + dd) * 2 + cch) * 4 + q) * 16 + i) * 4);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) av[t] = *reinterpret_cast<const f32x4*>(d2 + row[t] + 16 * cch);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = MFMA16(av[t][s], bw[s], acc[t]);
+  for (int t = 0; t < 3; ++t) {
+    const bf16x2v h01 = __builtin_convertvector(x01, bf16x2v), h23 = __builtin_convertvector(x23, bf16x2v);
+    pl[t] = (u32x2v){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    if (t < 2) {
+      x01 = x01 - __builtin_convertvector(h01, f32x2v);
+      x23 = x23 - __builtin_convertvector(h23, f32x2v);
     }
   }
-  float db1 = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = (mt0 + t) * 16 + 4 * q + r;
-      if (m < 100) {
-        const int idx = ((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * C1_LD + i;
-        const float g = c1[idx] > 0.f ? acc[t][r] : 0.f;
-        c1[idx] = g;
-        db1 += g;
-      }
-    }
-  return db1;
 }
 
-#ifdef UNREAL_ABLATE
-__device__ unsigned long long g_stamp_sum[16];
-#define STAMP(k)                                                                   \
-  do {                                                                             \
-    if (PHASES == 7 && blockIdx.x == 3 && threadIdx.x == 0) {                      \
-      unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
-      g_stamp_sum[k] += t_ - t_prev_;                                              \
-      t_prev_ = t_;                                                                \
-    }                                                                              \
-  } while (0)
-#else
-#define STAMP(k)
-#endif
+// two transposed 4-row blocks -> the 8 consecutive-k values of one 16x16x32 operand lane.  Lane 4*qq + pp of a
+// 16-lane group passes the address of block row qq (+ 8*pp bytes); it receives column (lane & 15) of the 4 rows.
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* a0, const unsigned char* a1) {
+  typedef s16x4v __attribute__((address_space(3))) * lds_p;
+  const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
+  const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
+  const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void stage_c1_planes(unsigned char* xp, int tid, const f32x4 (&pc1)[C1_V]) {
+#pragma unroll
+  for (int c = 0; c < C1_V; ++c) {
+    const int id = tid + 256 * c;
+    if (id < C1_POS * 4) {
+      u32x2v pl[3];
+      split4(pc1[c], pl);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPL + (id >> 2) * XROW + (id & 3) * 8) = pl[t];
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_d2_planes(unsigned char* zp, int tid, const f32x4 (&pd2)[D2_V], float (&adb2)[4]) {
+#pragma unroll
+  for (int c = 0; c < D2_V; ++c) {
+    const int id = tid + 256 * c;
+    if (id < C2_POS * 8) {
+      u32x2v pl[3];
+      split4(pd2[c], pl);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(zp + t * ZPL + (id >> 3) * ZROW + (id & 7) * 8) = pl[t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) adb2[e] += pd2[c][e];
+    }
+  }
+}
 
 template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
-__global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
-                                                          const int* __restrict__ frame_idx, float scale,
-                                                          const float* __restrict__ W2,
-                                                          const float* __restrict__ c1_saved,
-                                                          const float* __restrict__ d2_in, float* __restrict__ dW1,
-                                                          float* __restrict__ db1, float* __restrict__ dW2,
-                                                          float* __restrict__ db2) {
-  constexpr int GRP_BYTES = FR_LDS + C1_LDS * 4 + D2_ROWS * D2_LD * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + W2_ELEMS * 4];
-  const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
-  const int lane = threadIdx.x & 63, gw = gtid >> 6;
+__global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
+                                                             const int* __restrict__ frame_idx, float scale,
+                                                             const float* __restrict__ W2,
+                                                             const float* __restrict__ c1_saved,
+                                                             const float* __restrict__ d2_in, float* __restrict__ dW1,
+                                                             float* __restrict__ db1, float* __restrict__ dW2,
+                                                             float* __restrict__ db2) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  uint8_t* fr = smem + grp * GRP_BYTES;
-  float* c1 = reinterpret_cast<float*>(fr + FR_LDS);
-  float* d2 = c1 + C1_LDS;
-  float* w2t = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
-  // W2 for dgrad as [par(4)][dd(4)][cch(2)][q(4)][c(16)][s(4)]:
-  //   value W2[((pa+2da)*4 + (pb+2db))*16 + c][n], n = 16cch + 4q + s
-  for (int e = threadIdx.x; e < W2_ELEMS; e += 512) {
-    int s = e & 3, c = (e >> 2) & 15, qq = (e >> 6) & 3, cch = (e >> 8) & 1, dd = (e >> 9) & 3, par = e >> 11;
-    int ky = (par >> 1) + 2 * (dd >> 1), kx = (par & 1) + 2 * (dd & 1);
-    w2t[e] = W2[((ky * 4 + kx) * 16 + c) * 32 + 16 * cch + 4 * qq + s];
+  const int qq = i >> 2, pp = i & 3;       // transposed reads: lane 4qq + pp of a 16-lane group addresses block row qq
+  uint8_t* fr = smem;
+  unsigned char* xp = smem + FR_LDS;
+  unsigned char* zp = xp + X_BYTES;
+  const unsigned char* xzero = xp + 3 * XPL;
+  for (int e = tid; e < 3 * (ZROWS - C2_POS) * ZROW / 4; e += 256) {       // zero rows 81..95 of the three d2 planes
+    const int t = e / ((ZROWS - C2_POS) * ZROW / 4), w = e % ((ZROWS - C2_POS) * ZROW / 4);
+    reinterpret_cast<uint32_t*>(zp + t * ZPL + C2_POS * ZROW)[w] = 0u;
   }
-  for (int e = gtid; e < 3 * D2_LD; e += 256) d2[C2_POS * D2_LD + e] = 0.f;   // zero rows 81..83
+  if (tid < 16) reinterpret_cast<uint32_t*>(xp + 3 * XPL)[tid] = 0u;
+
+  // W2 fragments of phase (2), once per kernel: wave gw owns output parity (pa,pb) = (gw>>1, gw&1); tap dd = (da,db);
+  // A[row = c = i][k = n = 8q + j] = W2[pa+2da][pb+2db][c][n]
+  bf16x8 wa[4][3];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const int ky = (gw >> 1) + 2 * (dd >> 1), kx = (gw & 1) + 2 * (dd & 1);
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(W2 + ((ky * 4 + kx) * 16 + i) * 32 + 8 * q);
+    u32x2v lo[3], hi[3];
+    split4(wsrc[0], lo);
+    split4(wsrc[1], hi);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+      wa[dd][t] = __builtin_bit_cast(bf16x8, w4);
+    }
+  }
 
   f32x4 aw2[4][2];      // dW2 tiles: ky = gw, kx = 0..3, nt = 0..1
-  f32x4 aw1[3][4];      // dW1 tiles (g,t): patch elements m = 64g + 4*row + t, all 12 tiles, THIS wave's 100 positions
+  // dW1 tiles (g,t): patch elements m = 64g + 4*row + t.  Wave gw owns t = 2*(gw&1) + {0,1} (6 of the 12 tiles) over
+  // the positions [200*(gw>>1), +200) (half of K)
+  f32x4 aw1[3][2];
+  const int tset = gw & 1, khalf = gw >> 1;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -362,9 +408,9 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) aw1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // n = (gtid % 8) * 4 + e
-  float adb1 = 0.f;                       // channel i
+    for (int b = 0; b < 2; ++b) aw1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // n = (tid % 8) * 4 + e
+  float adb1[4] = {0.f, 0.f, 0.f, 0.f};   // channel 4q + e
 
   int off1[3];          // byte offset of patch element m = 64g + 4i in the 8x8x3 patch (4 consecutive m = one dword)
 #pragma unroll
@@ -373,145 +419,144 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
     off1[a] = (m / 24) * FRAME_ROW_BYTES + (m % 24);
   }
 
-  const int stride = gridDim.x * 2;
+  const int stride = gridDim.x;
   f32x4 pc1[C1_V], pd2[D2_V];
   u32x4 pfr[FR_V];
-  // prologue: stage c1 / d2 of this group's first frame
   {
-    const int n0 = blockIdx.x * 2 + grp;
-    if (n0 < N) {
-      frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, gtid, pfr);
-      frame_store(fr, gtid, pfr);
-      const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n0 * (C1_POS * C1_CH));
-      for (int id = gtid; id < C1_POS * 4; id += 256)
-        *reinterpret_cast<f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4) = cs[id];
-      const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)n0 * F2_DIM);
-      for (int id = gtid; id < C2_POS * 8; id += 256) {
-        f32x4 v = ds[id];
-        *reinterpret_cast<f32x4*>(d2 + (id >> 3) * D2_LD + (id & 7) * 4) = v;
+    const int n0 = blockIdx.x;           // the launch guarantees gridDim.x <= N
+    frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, tid, pfr);
+    frame_store(fr, tid, pfr);
+    const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n0 * (C1_POS * C1_CH));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) adb2[e] += v[e];
-      }
+    for (int c = 0; c < C1_V; ++c) {
+      int id = tid + 256 * c;
+      pc1[c] = cs[id < C1_POS * 4 ? id : tid];
     }
+    stage_c1_planes(xp, tid, pc1);
+    const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)n0 * F2_DIM);
+#pragma unroll
+    for (int c = 0; c < D2_V; ++c) {
+      int id = tid + 256 * c;
+      pd2[c] = ds[id < C2_POS * 8 ? id : tid];
+    }
+    stage_d2_planes(zp, tid, pd2, adb2);
   }
 
-#ifdef UNREAL_ABLATE
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
-#endif
-  for (int base = blockIdx.x * 2; base < N; base += stride) {
-    const int n = base + grp;
-    const bool valid = n < N;
+  for (int n = blockIdx.x; n < N; n += stride) {
     const int nn = n + stride;
     const bool has_next = nn < N;
-    STAMP(8);
-    __syncthreads();  // [S0] c1 / d2 of frame n staged
-    STAMP(0);
-    if (valid && (PHASES & 1)) {
-      // (1) conv2 wgrad; operands of step st+1 are read from LDS before the MFMAs of step st issue.
-      // The step loop is kept rolled (3 steps per trip): fully unrolled, the 21 lane-dependent address sets are
-      // loop-invariant across frames, get hoisted and spill.
-      float av[4], bv0, bv1;
-      {
-        const int ab = (gw * 20) * C1_LD + i + q * 2 * C1_LD;          // kp = q < 9
-        bv0 = d2[q * D2_LD + i]; bv1 = d2[q * D2_LD + 16 + i];
+    __syncthreads();  // [S0] planes / frame of frame n staged
+    if (PHASES & 1) {
+      // (1) conv2 wgrad: dW2[(ky=gw,kx,c)][n] += sum_p c1[2oy+ky][2ox+kx][c] * d2[p][n]; K = 81 positions as 3 x 32
+#pragma unroll 1     // rolled: unrolled, the three address sets are frame-invariant, get hoisted and spill
+      for (int ks = 0; ks < 3; ++ks) {
+        const int p0 = 32 * ks + 8 * q + qq, p1 = p0 + 4;                 // <= 95: rows 81.. of d2 are zero
+        const unsigned char* b0 = zp + p0 * ZROW + 8 * pp;
+        const unsigned char* b1 = zp + p1 * ZROW + 8 * pp;
+        bf16x8 bf[2][3];
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) av[kx] = c1[ab + kx * C1_LD];
-      }
-#pragma unroll 1
-      for (int sb = 0; sb < 21; sb += 3) {
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          const int st = sb + u;
-          float an[4], bn0, bn1;
-          {
-            const int kpb = min(4 * (st + 1) + q, D2_ROWS - 1);   // rows 81..83 of d2 are zero; st = 20 reads a dummy
-            const int kp = min(kpb, C2_POS - 1);
-            const int ab = ((2 * (kp / 9) + gw) * 20 + 2 * (kp % 9)) * C1_LD + i;
-            bn0 = d2[kpb * D2_LD + i]; bn1 = d2[kpb * D2_LD + 16 + i];
+          for (int t = 0; t < 3; ++t) bf[nt][t] = tr_pair(b0 + t * ZPL + 32 * nt, b1 + t * ZPL + 32 * nt);
+        const int c0 = min(p0, C2_POS - 1), c1i = min(p1, C2_POS - 1);   // K padding: any valid c1 row (d2 row is 0)
+        const unsigned char* a0 = xp + ((2 * (c0 / 9) + gw) * 20 + 2 * (c0 % 9)) * XROW + 8 * pp;
+        const unsigned char* a1 = xp + ((2 * (c1i / 9) + gw) * 20 + 2 * (c1i % 9)) * XROW + 8 * pp;
 #pragma unroll
-            for (int kx = 0; kx < 4; ++kx) an[kx] = c1[ab + kx * C1_LD];
-          }
+        for (int kx = 0; kx < 4; ++kx) {
+          bf16x8 af[3];
 #pragma unroll
-          for (int kx = 0; kx < 4; ++kx) {
-            aw2[kx][0] = MFMA16(av[kx], bv0, aw2[kx][0]);
-            aw2[kx][1] = MFMA16(av[kx], bv1, aw2[kx][1]);
-          }
-#pragma unroll
-          for (int kx = 0; kx < 4; ++kx) av[kx] = an[kx];
-          bv0 = bn0; bv1 = bn1;
+          for (int t = 0; t < 3; ++t) af[t] = tr_pair(a0 + t * XPL + kx * XROW, a1 + t * XPL + kx * XROW);
+          SPLIT_MMA(af, bf[0], aw2[kx][0]);
+          SPLIT_MMA(af, bf[1], aw2[kx][1]);
         }
       }
     }
-    STAMP(1);
-    __syncthreads();  // [S1] all reads of c1 done before the in-place dgrad overwrite
-    STAMP(2);
+    __syncthreads();  // [S1] all reads of the c1 planes done before d1 overwrites them
 
-    if (valid && (PHASES & 2)) {
-      // (2) conv2 dgrad: wave gw owns output parity gw; its 7 position tiles as 4 + 3 independent accumulators
-      adb1 += dgrad_tiles<4>(d2, c1, w2t, gw, 0, i, q);
-      adb1 += dgrad_tiles<3>(d2, c1, w2t, gw, 4, i, q);
+    if (PHASES & 2) {
+      // (2) conv2 dgrad, wave gw = output parity: d1^T[c][m] = sum_{dd,n} W2[pa+2da][pb+2db][c][n] * d2[a-da][b-db][n],
+      // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16)
+#pragma unroll 1
+      for (int t = 0; t < 7; ++t) {
+        const int m = min(16 * t + i, 99);
+        const int ma = m / 10, mb = m - 10 * ma;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const int y = ma - (dd >> 1), x = mb - (dd & 1);
+          const int row = (y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS;
+          bf16x8 bfr[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            bfr[pl] = *reinterpret_cast<const bf16x8*>(zp + pl * ZPL + row * ZROW + 16 * q);
+          SPLIT_MMA(wa[dd], bfr, acc);
+        }
+        // acc[r] = d1 of channel 4q + r at position m: ReLU mask from the c1 hi terms it replaces, split, store
+        const int pos = (2 * ma + (gw >> 1)) * 20 + 2 * mb + (gw & 1);
+        unsigned char* dst = xp + pos * XROW + 8 * q;
+        const u32x2v hi = *reinterpret_cast<const u32x2v*>(dst);
+        f32x4 g;
+        g[0] = (hi[0] & 0xffffu) ? acc[0] : 0.f;
+        g[1] = (hi[0] >> 16) ? acc[1] : 0.f;
+        g[2] = (hi[1] & 0xffffu) ? acc[2] : 0.f;
+        g[3] = (hi[1] >> 16) ? acc[3] : 0.f;
+        if (16 * t + i < 100) {
+          u32x2v pl[3];
+          split4(g, pl);
+#pragma unroll
+          for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x2v*>(dst + u * XPL) = pl[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) adb1[e] += g[e];
+        }
+      }
     }
-    STAMP(3);
-    __syncthreads();  // [S2] c1 holds d1; frame staged; d2 free
-    STAMP(4);
+    __syncthreads();  // [S2] d1 planes complete; d2 planes free
 
     if (has_next) {   // fetch the next frame's uint8 image, c1 and d2 behind phase (3)
-      frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, gtid, pfr);
+      frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, tid, pfr);
       const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)nn * (C1_POS * C1_CH));
 #pragma unroll
       for (int c = 0; c < C1_V; ++c) {
-        int id = gtid + 256 * c;
-        pc1[c] = cs[id < C1_POS * 4 ? id : gtid];
+        int id = tid + 256 * c;
+        pc1[c] = cs[id < C1_POS * 4 ? id : tid];
       }
       const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)nn * F2_DIM);
 #pragma unroll
       for (int c = 0; c < D2_V; ++c) {
-        int id = gtid + 256 * c;
-        pd2[c] = ds[id < C2_POS * 8 ? id : gtid];
+        int id = tid + 256 * c;
+        pd2[c] = ds[id < C2_POS * 8 ? id : tid];
       }
     }
-    if (valid && (PHASES & 4)) {
-      // (3) conv1 wgrad as EXACT-PRODUCT bf16 MFMAs (same argument as the forward conv1): A = uint8 pixels
-      // (exact in bf16), B = d1 split into three bf16 terms (hi/mid/lo by truncation, residuals exact), three
-      // v_mfma_f32_16x16x32_bf16 per 32-position chunk, fp32 accumulation.  K (positions) is split over the 4 waves:
-      // wave gw owns output rows 5gw..5gw+4 (100 positions = 4 chunks of 32 slots, 28 of them zero padding) and ALL
-      // 12 row tiles; tile (g,t) holds patch elements m = 64g + 4*row + t so one aligned dword of the frame per
-      // position feeds 4 tiles.  Lane (i, q) supplies slots s = 32kc + 8q + j, j = 0..7, of row i (A) / channel i (B).
-      const uint8_t* frow = fr + (4 * 5 * gw) * FRAME_ROW_BYTES;
+    if (PHASES & 4) {
+      // (3) conv1 wgrad: A = uint8 pixels (exact in bf16), B = the three d1 planes (transposed reads: K = position),
+      // fp32 accumulation.  Wave gw: positions [200*khalf, +200) as 7 chunks of 32 slots (24 of the last are zero
+      // padding) x its 6 row tiles; tile (g,t) holds patch elements m = 64g + 4*row + t so one aligned dword of the
+      // frame per position feeds the wave's two t.
+      const int pbase = 200 * khalf;
 #pragma unroll 1
-      for (int kc = 0; kc < 4; ++kc) {
-        u32x4 bpl[3];
+      for (int kc = 0; kc < 7; ++kc) {
+        bf16x8 bpl[3];
         {
-          uint32_t t0[8], t1[8], t2[8];
+          const int s0 = 32 * kc + 8 * q + qq, s1 = s0 + 4;
+          const unsigned char* b0 = s0 < 200 ? xp + (pbase + s0) * XROW + 8 * pp : xzero + 8 * pp;
+          const unsigned char* b1 = s1 < 200 ? xp + (pbase + s1) * XROW + 8 * pp : xzero + 8 * pp;
+          const int po0 = s0 < 200 ? XPL : 0, po1 = s1 < 200 ? XPL : 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int sl = 32 * kc + 8 * q + j;
-            const float v = sl < 100 ? c1[(100 * gw + sl) * C1_LD + i] : 0.f;
-            t0[j] = __float_as_uint(v) & 0xffff0000u;
-            const float r1 = v - __uint_as_float(t0[j]);
-            t1[j] = __float_as_uint(r1) & 0xffff0000u;
-            t2[j] = __float_as_uint(r1 - __uint_as_float(t1[j]));     // <= 8 significant bits left: exact in bf16
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            bpl[0][e] = __builtin_amdgcn_perm(t0[2 * e + 1], t0[2 * e], 0x07060302u);
-            bpl[1][e] = __builtin_amdgcn_perm(t1[2 * e + 1], t1[2 * e], 0x07060302u);
-            bpl[2][e] = __builtin_amdgcn_perm(t2[2 * e + 1], t2[2 * e], 0x07060302u);
-          }
+          for (int t = 0; t < 3; ++t) bpl[t] = tr_pair(b0 + t * po0, b1 + t * po1);
         }
         int pofs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int sl = min(32 * kc + 8 * q + j, 99);                // padding slots: any valid address (B = 0)
-          pofs[j] = (4 * (sl / 20)) * FRAME_ROW_BYTES + 12 * (sl % 20);
+          const int ps = pbase + min(32 * kc + 8 * q + j, 199);       // padding slots: any valid address (B = 0)
+          pofs[j] = (4 * (ps / 20)) * FRAME_ROW_BYTES + 12 * (ps % 20);
         }
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
           uint32_t w[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const uint32_t*>(frow + pofs[j] + off1[g]);
+          for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const uint32_t*>(fr + pofs[j] + off1[g]) >> (16 * tset);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < 2; ++t) {
             u32x4 pk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -520,39 +565,22 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
               pk[e] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
             }
             const bf16x8 av = __builtin_bit_cast(bf16x8, pk);
-#pragma unroll
-            for (int tm = 0; tm < 3; ++tm)
-              aw1[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, bpl[tm]), aw1[g][t],
-                                                                  0, 0, 0);
+            aw1[g][t] = MFMA_BF16(av, bpl[2], aw1[g][t]);
+            aw1[g][t] = MFMA_BF16(av, bpl[1], aw1[g][t]);
+            aw1[g][t] = MFMA_BF16(av, bpl[0], aw1[g][t]);
           }
         }
       }
     }
+    if (has_next) stage_d2_planes(zp, tid, pd2, adb2);
+    __syncthreads();  // [S3] phase (3) finished reading the d1 planes and the frame
     if (has_next) {
-#pragma unroll
-      for (int c = 0; c < D2_V; ++c) {
-        int id = gtid + 256 * c;
-        if (id < C2_POS * 8) {
-          *reinterpret_cast<f32x4*>(d2 + (id >> 3) * D2_LD + (id & 7) * 4) = pd2[c];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) adb2[e] += pd2[c][e];
-        }
-      }
-    }
-    STAMP(5);
-    __syncthreads();  // [S3] phase (3) finished reading c1 (d1)
-    STAMP(6);
-    if (has_next) {
-#pragma unroll
-      for (int c = 0; c < C1_V; ++c) {
-        int id = gtid + 256 * c;
-        if (id < C1_POS * 4) *reinterpret_cast<f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4) = pc1[c];
-      }
-      frame_store(fr, gtid, pfr);
+      stage_c1_planes(xp, tid, pc1);
+      frame_store(fr, tid, pfr);
     }
   }
 
-  // flush accumulators
+  // flush accumulators (C/D map of the 16x16 MFMAs: col = lane & 15, row = 4 * (lane >> 4) + r)
 #pragma unroll
   for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
@@ -563,15 +591,21 @@ __global__ __launch_bounds__(512) void encoder_bwd_kernel(int N, const uint8_t* 
 #pragma unroll
   for (int g = 0; g < 3; ++g)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dW1 + (64 * g + 4 * (4 * q + r) + t) * 16 + i, scale * aw1[g][t][r]);
-  // db1: lanes with equal i (channel) across q
-  adb1 += __shfl_xor(adb1, 16, 64);
-  adb1 += __shfl_xor(adb1, 32, 64);
-  if (q == 0) atomicAdd(db1 + i, adb1);
-  // db2: threads with equal (gtid % 8) own the same 4 columns
+        atomicAdd(dW1 + (64 * g + 4 * (4 * q + r) + 2 * tset + t) * 16 + i, scale * aw1[g][t][r]);
+  // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = adb1[e];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    if (i == 0) atomicAdd(db1 + 4 * q + e, v);
+  }
+  // db2: threads with equal (tid % 8) own the same 4 columns
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v = adb2[e];
@@ -601,27 +635,18 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
                        void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W2 || !c1_saved || !d2 || !dW1 || !db1 || !dW2 || !db2)
     return UNREAL_EINVAL;
-  int blocks = min((N + 1) / 2, 256);
-  hipLaunchKernelGGL(encoder_bwd_kernel<7>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, frame_idx,
+  int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
+  hipLaunchKernelGGL(encoder_bwd_kernel<7>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
                      frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2);
   return unreal_launch_status();
 }
 
 #ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
-int exp_read_stamps(unsigned long long* host16, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_stamp_sum), sizeof(unsigned long long) * 16);
-  if (reset) {
-    unsigned long long z[16] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z));
-  }
-  return 0;
-}
 int exp_encoder_bwd_phases(int phases, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
                            const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
                            float* db2, void* stream) {
-  int blocks = min((N + 1) / 2, 256);
-#define LAUNCH_(P) hipLaunchKernelGGL(encoder_bwd_kernel<P>, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, \
+  int blocks = min(N, 512);
+#define LAUNCH_(P) hipLaunchKernelGGL(encoder_bwd_kernel<P>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, \
                                       frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2)
   switch (phases) {
     case 0: LAUNCH_(0); break;
