@@ -35,8 +35,15 @@ sys.path.insert(0, ROOT)
 # algorithmic work per launch unit (DESIGN.md section "Kernels"); MACs per frame
 ENC_FWD_MAC = 400 * 192 * 16 + 81 * 256 * 32                     # conv1 + conv2 forward
 ENC_BWD_MAC = 81 * 256 * 32 * 2 + 400 * 192 * 16                 # conv2 wgrad + dgrad, conv1 wgrad
+# encoder_bwd runs every product on the bf16 matrix cores with split operands: conv2 wgrad / dgrad take 6 bf16 passes per
+# fp32 product, conv1 wgrad 3 (the uint8 pixel is exact in one term).  Its ceiling is the dense bf16 MFMA peak over
+# those passes: BLENDED fp32-equivalent peak = algorithmic MACs / (bf16 pass-MACs / 2500 TF)
+ENC_BWD_BF16_PASS_MAC = 81 * 256 * 32 * 2 * 6 + 400 * 192 * 16 * 3
+BF16_MFMA_PEAK_TFLOPS = 2500.0                                   # MI355X_MICROARCH.md, Peak BF16 MFMA (dense)
+ENC_BWD_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS * ENC_BWD_MAC / ENC_BWD_BF16_PASS_MAC      # ~549 fp32-equivalent TFLOP/s
 FP32_MFMA_PEAK_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, Peak FP32 (matrix)
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = "r02_pmc_bench.json"                                  # in-situ rocprofv3 --pmc passes of THIS program
 
 
 def build_trainer(args, rank, world, device):
@@ -163,16 +170,16 @@ def main():
     mac = ENC_BWD_MAC if "bwd" in args.timed_kernel else ENC_FWD_MAC
     avg_ms = kt["ms"] / max(kt["launches"], 1)
     achieved = (2.0 * mac * frames_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    # HBM traffic per launch: PMC counters cannot be read from inside this process; the per-frame figure comes
-    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_encoder.json, corrected
-    # as MI355X_MICROARCH.md prescribes) scaled by the frames one launch processed.
+    # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r02_pmc_bench.json,
+    # corrected as MI355X_MICROARCH.md prescribes: FETCH doubled), mean over the launches of its timed calls.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_encoder.json")))
-        key = "encoder_bwd" if "bwd" in args.timed_kernel else "encoder_fwd_save_c1"
-        traffic = pmc[key]["hbm_bytes_per_frame"] * frames_per_launch
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+        traffic = pmc[args.timed_kernel.replace("unreal_", "") + "_kernel"]["hbm_bytes_per_launch"]
     except Exception:
         pass
+    peak = ENC_BWD_PEAK_TFLOPS if "bwd" in args.timed_kernel else FP32_MFMA_PEAK_TFLOPS
     out = {
         "metric": "env-steps/sec (whole node), UNREAL maze 84x84",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,8 +193,12 @@ def main():
                    "all-reduce (%s)" % (world, backend) if world > 1 else "single GPU", "replay_fill_s": t_fill,
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
         "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass)",
+                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "peak_note": "fp32-equivalent: dense bf16 MFMA peak (2500 TF) over the kernel's bf16 passes (conv2 "
+                                  "wgrad + dgrad x6, conv1 wgrad x3); against the fp32 MFMA peak (157.3) the fraction is "
+                                  "%.3f" % (achieved / FP32_MFMA_PEAK_TFLOPS),
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (in-situ PMC passes of bench.py, "
+                                                         "profiles/%s)" % PMC_FILE,
                      "algorithmic_bytes_per_launch": 57136.0 * frames_per_launch,
                      "launches": kt["launches"], "avg_launch_ms": avg_ms,
                      "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),

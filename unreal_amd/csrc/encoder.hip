@@ -263,17 +263,22 @@ __global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* 
 // >= 2^-16 in fp32 (dropped pairs < 2^-24 |ab|); the uint8 pixel is exact in one bf16 term (3 MFMAs per tile).
 // That is 6/16 of the fp32 MFMA's matrix-pipe time for phases (1)-(2).
 //
-// Organisation: one frame per 256-thread workgroup at a time, TWO workgroups per CU (78 KB of LDS each) that run
-// independently -- one's staging / epilogue VALU overlaps the other's MFMAs on the same SIMDs.  LDS per workgroup:
-//   FR  uint8 frame [84][252]
+// Organisation: one frame per 256-thread workgroup at a time, TWO workgroups per CU (exactly 80 KiB of LDS each) that
+// run independently -- one's staging / epilogue VALU overlaps the other's MFMAs on the same SIMDs.  LDS per workgroup:
+//   Y   [0, 42816): FR = the uint8 frame as it comes from HBM (LDS-DMA, issued at the top of the frame's iteration and
+//       waited for only before phase (3)) | spare | Z = d2 planes [3][111 rows][32 n] bf16 with a ZERO HALO: position
+//       (y,x) lives in row (y+1)*10 + (x+1), rows of y = -1, y = 9 and x = -1 are zero (x = 9 wraps onto the next
+//       row's x = -1), so the tap (a-da, b-db) of output position m = 10a + b is row m + 11 - (10da + db): phase (2)
+//       addresses its operands with compile-time offsets from one lane-constant base, and "outside" taps read zeros.
+//       Between phases (2) and (3) the frame is expanded to bf16 [84][252] over the whole of Y (FR and Z are dead by
+//       then), so phase (3) needs no conversion in its loop.
 //   X   c1 planes [3][400 pos][16 ch] bf16; phase (2) overwrites them IN PLACE with the d1 planes (the ReLU mask of
 //       an element is read from its own c1 hi term just before it is overwritten) + one zero row
-//   Z   d2 planes [3][96 pos][32 n] bf16, rows 81..95 zero (K padding of phase (1), "outside" taps of phase (2))
-// Reductions over POSITIONS (phases 1 and 3: the position is the row index of both LDS images) take both operands
+// Reductions over POSITIONS (phases 1 and 3: the position is the row index of the LDS images) take both operands
 // through ds_read_b64_tr_b16 (a 4-row x 16-column block, transposed in flight; each lane supplies the address of
 // one row, so the strided conv taps need no im2col copy); phase (2) reduces over d2's channel index, contiguous in
 // a row: plain 16-byte fragment reads, and its weight fragments never leave the registers.
-// The NEXT frame's uint8 image, c1 and d2 are fetched into registers behind phase (3) and written to LDS after it.
+// The NEXT frame's c1 and d2 are fetched into registers behind phase (3) and split into the planes after it.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -281,17 +286,41 @@ typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 typedef short s16x4v __attribute__((ext_vector_type(4)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
 
+#ifndef BWD_UNROLL_KS     // loop unrolling of the three phases (A/B-tested on the device: tools/exp/ablate_encoder_bwd.py)
+#define BWD_UNROLL_KS 1
+#endif
+#ifndef BWD_UNROLL_T
+#define BWD_UNROLL_T 1
+#endif
+#ifndef BWD_UNROLL_KC
+#define BWD_UNROLL_KC 1
+#endif
 constexpr int C1_V = (C1_POS * 4 + 255) / 256;   // f32x4 per thread for one c1 image (7)
 constexpr int D2_V = (C2_POS * 8 + 255) / 256;   // f32x4 per thread for one d2 image (3)
 constexpr int XROW = 32;                         // bytes per conv1 position in a plane (16 bf16)
 constexpr int XPL = C1_POS * XROW;               // 12800
 constexpr int X_BYTES = 3 * XPL + 64;            // + 64 zero bytes
 constexpr int ZROW = 64;                         // bytes per conv2 position in a plane (32 bf16)
-constexpr int ZROWS = 96;
-constexpr int ZPL = ZROWS * ZROW;                // 6144
-constexpr int Z_BYTES = 3 * ZPL;                 // 18432
-constexpr int BWD_LDS = FR_LDS + X_BYTES + Z_BYTES;   // 78080: two workgroups per CU
+constexpr int ZROWS = 111;                       // 11 x 10 halo grid + row 110 (tap (9,9) of position 99)
+constexpr int ZPL = ZROWS * ZROW;                // 7104
+constexpr int Z_BYTES = 3 * ZPL;                 // 21312
+constexpr int Z_HALO = 30;                       // zero rows: 0..9 (y = -1), 10,20..90 (x = -1), 100..110 (y = 9)
+constexpr int FR_CHUNKS = FRAME_BYTES / 16;      // 1323 16-byte pieces of a frame
+constexpr int FR_DMA = (FR_CHUNKS + 63) / 64;    // 21 wave-wide LDS-DMA instructions (1 KiB each; the last one overshoots)
+constexpr int Z_OFF = FR_LDS + 320;              // 21504: the DMA overshoot (21504 bytes written) stays in the spare
+constexpr int X_OFF = Z_OFF + Z_BYTES;           // 42816 = size of Y
+constexpr int BWD_LDS = X_OFF + X_BYTES;         // 81280: two workgroups per CU
+static_assert(FR_DMA * 1024 <= Z_OFF && 2 * FRAME_BYTES <= X_OFF, "frame images must fit Y");
 static_assert(2 * BWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS");
+
+// workgroup barrier that does NOT drain the vector-memory counter (an LDS-DMA stays in flight across it): LDS
+// writes / reads of this wave are retired first, the compiler may not move memory accesses across it
+#define WG_BARRIER()                                      \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("" ::: "memory");                        \
+  } while (0)
 
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 // six term pairs of one product tile, smallest first
@@ -304,6 +333,17 @@ static_assert(2 * BWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS")
     C = MFMA_BF16(A[0], B[1], C);     \
     C = MFMA_BF16(A[0], B[0], C);     \
   } while (0)
+
+// LDS bank spreading (ds_read_b64_tr_b16 serves a wave as two 32-lane halves over 64 banks = one 256-byte window):
+//  * the K index of a 32-deep chunk is dealt to the lanes so that one half-wave reads 8 CONSECUTIVE positions:
+//    lane (q, qq) of read h takes position 16(q>>1) + 8h + 4(q&1) + qq (both operands use the same deal);
+//  * X rows (32 B) are stored at row p ^ ((p>>3)&1): 8 consecutive rows AND 8 rows two apart (the stride-2 conv2 taps)
+//    then fall into 8 different 32-byte slots of the window;
+//  * Z rows (64 B) swap their 32-byte halves when bit 2 of the row index is set: the 8 consecutive rows of a
+//    half-wave's n-tile read fall into 8 different slots.
+// Without these every transposed read of phases (1) and (3) was 2-way conflicted (PMC: 57 % of the LDS cycles).
+__device__ __forceinline__ int xrow(int p) { return p ^ ((p >> 3) & 1); }
+__device__ __forceinline__ int kdeal(int q, int qq) { return 16 * (q >> 1) + 4 * (q & 1) + qq; }
 
 // 4 fp32 -> three planes of 4 bf16 (round to nearest even; x = pl0 + pl1 + pl2 exactly)
 __device__ __forceinline__ void split4(const f32x4& v, u32x2v (&pl)[3]) {
@@ -337,24 +377,45 @@ __device__ __forceinline__ void stage_c1_planes(unsigned char* xp, int tid, cons
       u32x2v pl[3];
       split4(pc1[c], pl);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPL + (id >> 2) * XROW + (id & 3) * 8) = pl[t];
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPL + xrow(id >> 2) * XROW + (id & 3) * 8) = pl[t];
     }
   }
 }
 
 __device__ __forceinline__ void stage_d2_planes(unsigned char* zp, int tid, const f32x4 (&pd2)[D2_V], float (&adb2)[4]) {
+  // the halo rows of the three planes are zero (the bf16 frame image of the previous frame lay over them)
+  for (int e = tid; e < 3 * Z_HALO * 4; e += 256) {
+    const int t = e / (Z_HALO * 4), k = (e >> 2) % Z_HALO;
+    const int r = k < 10 ? k : (k < 19 ? (k - 9) * 10 : 81 + k);
+    *reinterpret_cast<u32x4*>(zp + t * ZPL + r * ZROW + (e & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
 #pragma unroll
   for (int c = 0; c < D2_V; ++c) {
     const int id = tid + 256 * c;
     if (id < C2_POS * 8) {
       u32x2v pl[3];
       split4(pd2[c], pl);
+      const int pos = id >> 3, r = (pos / 9 + 1) * 10 + pos % 9 + 1;
 #pragma unroll
-      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(zp + t * ZPL + (id >> 3) * ZROW + (id & 7) * 8) = pl[t];
+      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(zp + t * ZPL + r * ZROW + ((id & 7) ^ (r & 4)) * 8) = pl[t];
 #pragma unroll
       for (int e = 0; e < 4; ++e) adb2[e] += pd2[c][e];
     }
   }
+}
+
+// One wave-wide LDS-DMA: 64 x 16 bytes, lane l's source -> LDS byte address lds_dst + 16 l (M0 = wave-uniform base).
+// Issued from inline asm ON PURPOSE: hipcc orders every later LDS read of the same __shared__ array behind a DMA it
+// can see (s_waitcnt vmcnt(0) at the first ds_read of phase (1)), which would expose the HBM latency the DMA is there
+// to hide.  The kernel waits for it itself (s_waitcnt vmcnt(0) + barrier before phase (3)); no compiler-counted
+// vector load is in flight while a DMA is (the prefetch loads are issued after that wait and consumed before the next
+// DMA), so the compiler's own vmcnt bookkeeping stays exact.
+__device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
 }
 
 template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
@@ -369,14 +430,11 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
   const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int qq = i >> 2, pp = i & 3;       // transposed reads: lane 4qq + pp of a 16-lane group addresses block row qq
-  uint8_t* fr = smem;
-  unsigned char* xp = smem + FR_LDS;
-  unsigned char* zp = xp + X_BYTES;
+  unsigned char* yp = smem;                 // uint8 frame (DMA) -> bf16 frame image
+  const unsigned lds_y = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned char* zp = smem + Z_OFF;
+  unsigned char* xp = smem + X_OFF;
   const unsigned char* xzero = xp + 3 * XPL;
-  for (int e = tid; e < 3 * (ZROWS - C2_POS) * ZROW / 4; e += 256) {       // zero rows 81..95 of the three d2 planes
-    const int t = e / ((ZROWS - C2_POS) * ZROW / 4), w = e % ((ZROWS - C2_POS) * ZROW / 4);
-    reinterpret_cast<uint32_t*>(zp + t * ZPL + C2_POS * ZROW)[w] = 0u;
-  }
   if (tid < 16) reinterpret_cast<uint32_t*>(xp + 3 * XPL)[tid] = 0u;
 
   // W2 fragments of phase (2), once per kernel: wave gw owns output parity (pa,pb) = (gw>>1, gw&1); tap dd = (da,db);
@@ -397,35 +455,31 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
   }
 
   f32x4 aw2[4][2];      // dW2 tiles: ky = gw, kx = 0..3, nt = 0..1
-  // dW1 tiles (g,t): patch elements m = 64g + 4*row + t.  Wave gw owns t = 2*(gw&1) + {0,1} (6 of the 12 tiles) over
-  // the positions [200*(gw>>1), +200) (half of K)
-  f32x4 aw1[3][2];
+  // dW1 tiles T = 0..11: patch elements m = 16T + row (a tile row = one (ky, kx, cin); 4 consecutive m are 8
+  // contiguous bytes of the bf16 frame image).  Wave gw owns the 6 tiles 6*(gw&1) + u over the positions
+  // [200*(gw>>1), +200) (half of K)
+  f32x4 aw1[6];
   const int tset = gw & 1, khalf = gw >> 1;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) aw2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) aw1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 6; ++a) aw1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // n = (tid % 8) * 4 + e
   float adb1[4] = {0.f, 0.f, 0.f, 0.f};   // channel 4q + e
 
-  int off1[3];          // byte offset of patch element m = 64g + 4i in the 8x8x3 patch (4 consecutive m = one dword)
+  int toff[6];          // byte offset (bf16 image) of patch elements 16T + 4pp .. +3 relative to the patch origin
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int m = 64 * a + 4 * i;
-    off1[a] = (m / 24) * FRAME_ROW_BYTES + (m % 24);
+  for (int u = 0; u < 6; ++u) {
+    const int m0 = 16 * (6 * tset + u) + 4 * pp;
+    toff[u] = ((m0 / 24) * FRAME_ROW_BYTES + (m0 % 24)) * 2;
   }
 
   const int stride = gridDim.x;
   f32x4 pc1[C1_V], pd2[D2_V];
-  u32x4 pfr[FR_V];
   {
     const int n0 = blockIdx.x;           // the launch guarantees gridDim.x <= N
-    frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, tid, pfr);
-    frame_store(fr, tid, pfr);
     const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n0 * (C1_POS * C1_CH));
 #pragma unroll
     for (int c = 0; c < C1_V; ++c) {
@@ -445,55 +499,70 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
   for (int n = blockIdx.x; n < N; n += stride) {
     const int nn = n + stride;
     const bool has_next = nn < N;
-    __syncthreads();  // [S0] planes / frame of frame n staged
+    {   // uint8 frame n -> FR by LDS-DMA (lane-linear 1 KiB pieces); first needed by phase (3)
+      const uint8_t* src = frames + (size_t)frame_idx[n] * FRAME_BYTES;
+      for (int kk = gw; kk < FR_DMA; kk += 4) {
+        const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);      // the overshoot of the last piece re-reads the last chunk
+        glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_y + 1024 * kk));
+      }
+    }
+    // an opaque 0, new every frame: added to the lane-dependent position indices below so that the address sets of
+    // the unrolled phases are NOT frame-invariant (hoisted out of the frame loop they occupy ~80 registers and spill)
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    WG_BARRIER();     // [S0] planes of frame n staged
     if (PHASES & 1) {
       // (1) conv2 wgrad: dW2[(ky=gw,kx,c)][n] += sum_p c1[2oy+ky][2ox+kx][c] * d2[p][n]; K = 81 positions as 3 x 32
-#pragma unroll 1     // rolled: unrolled, the three address sets are frame-invariant, get hoisted and spill
+#pragma unroll BWD_UNROLL_KS
       for (int ks = 0; ks < 3; ++ks) {
-        const int p0 = 32 * ks + 8 * q + qq, p1 = p0 + 4;                 // <= 95: rows 81.. of d2 are zero
-        const unsigned char* b0 = zp + p0 * ZROW + 8 * pp;
-        const unsigned char* b1 = zp + p1 * ZROW + 8 * pp;
+        const int p0 = 32 * ks + kdeal(q, qq) + zero, p1 = p0 + 8;        // <= 95: K padding reads the zero row 0
+        const int z0 = p0 < C2_POS ? (p0 / 9 + 1) * 10 + p0 % 9 + 1 : 0;
+        const int z1 = p1 < C2_POS ? (p1 / 9 + 1) * 10 + p1 % 9 + 1 : 0;
         bf16x8 bf[2][3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+          const unsigned char* b0 = zp + z0 * ZROW + ((4 * nt + pp) ^ (z0 & 4)) * 8;
+          const unsigned char* b1 = zp + z1 * ZROW + ((4 * nt + pp) ^ (z1 & 4)) * 8;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) bf[nt][t] = tr_pair(b0 + t * ZPL + 32 * nt, b1 + t * ZPL + 32 * nt);
+          for (int t = 0; t < 3; ++t) bf[nt][t] = tr_pair(b0 + t * ZPL, b1 + t * ZPL);
+        }
         const int c0 = min(p0, C2_POS - 1), c1i = min(p1, C2_POS - 1);   // K padding: any valid c1 row (d2 row is 0)
-        const unsigned char* a0 = xp + ((2 * (c0 / 9) + gw) * 20 + 2 * (c0 % 9)) * XROW + 8 * pp;
-        const unsigned char* a1 = xp + ((2 * (c1i / 9) + gw) * 20 + 2 * (c1i % 9)) * XROW + 8 * pp;
+        const int r0 = (2 * (c0 / 9) + gw) * 20 + 2 * (c0 % 9), r1 = (2 * (c1i / 9) + gw) * 20 + 2 * (c1i % 9);
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
+          const unsigned char* a0 = xp + xrow(r0 + kx) * XROW + 8 * pp;
+          const unsigned char* a1 = xp + xrow(r1 + kx) * XROW + 8 * pp;
           bf16x8 af[3];
 #pragma unroll
-          for (int t = 0; t < 3; ++t) af[t] = tr_pair(a0 + t * XPL + kx * XROW, a1 + t * XPL + kx * XROW);
+          for (int t = 0; t < 3; ++t) af[t] = tr_pair(a0 + t * XPL, a1 + t * XPL);
           SPLIT_MMA(af, bf[0], aw2[kx][0]);
           SPLIT_MMA(af, bf[1], aw2[kx][1]);
         }
       }
     }
-    __syncthreads();  // [S1] all reads of the c1 planes done before d1 overwrites them
+    WG_BARRIER();     // [S1] all reads of the c1 planes done before d1 overwrites them
 
     if (PHASES & 2) {
       // (2) conv2 dgrad, wave gw = output parity: d1^T[c][m] = sum_{dd,n} W2[pa+2da][pb+2db][c][n] * d2[a-da][b-db][n],
-      // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16)
-#pragma unroll 1
+      // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16).  Tap (da,db) of position m is halo
+      // row m + 11 - (10da + db).
+#pragma unroll BWD_UNROLL_T
       for (int t = 0; t < 7; ++t) {
-        const int m = min(16 * t + i, 99);
+        const int m = min(16 * t + i + zero, 99);
         const int ma = m / 10, mb = m - 10 * ma;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
-          const int y = ma - (dd >> 1), x = mb - (dd & 1);
-          const int row = (y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS;
+          const int r = m + 11 - 10 * (dd >> 1) - (dd & 1);
+          const unsigned char* zt = zp + r * ZROW + (q ^ ((r & 4) >> 1)) * 16;
           bf16x8 bfr[3];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            bfr[pl] = *reinterpret_cast<const bf16x8*>(zp + pl * ZPL + row * ZROW + 16 * q);
+          for (int pl = 0; pl < 3; ++pl) bfr[pl] = *reinterpret_cast<const bf16x8*>(zt + pl * ZPL);
           SPLIT_MMA(wa[dd], bfr, acc);
         }
         // acc[r] = d1 of channel 4q + r at position m: ReLU mask from the c1 hi terms it replaces, split, store
         const int pos = (2 * ma + (gw >> 1)) * 20 + 2 * mb + (gw & 1);
-        unsigned char* dst = xp + pos * XROW + 8 * q;
+        unsigned char* dst = xp + xrow(pos) * XROW + 8 * q;
         const u32x2v hi = *reinterpret_cast<const u32x2v*>(dst);
         f32x4 g;
         g[0] = (hi[0] & 0xffffu) ? acc[0] : 0.f;
@@ -510,10 +579,10 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
         }
       }
     }
-    __syncthreads();  // [S2] d1 planes complete; d2 planes free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the frame have landed in FR
+    WG_BARRIER();     // [S2] d1 planes complete; d2 planes dead; FR complete
 
-    if (has_next) {   // fetch the next frame's uint8 image, c1 and d2 behind phase (3)
-      frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, tid, pfr);
+    if (has_next) {   // fetch the next frame's c1 and d2 behind phase (3)
       const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)nn * (C1_POS * C1_CH));
 #pragma unroll
       for (int c = 0; c < C1_V; ++c) {
@@ -528,55 +597,61 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
       }
     }
     if (PHASES & 4) {
-      // (3) conv1 wgrad: A = uint8 pixels (exact in bf16), B = the three d1 planes (transposed reads: K = position),
-      // fp32 accumulation.  Wave gw: positions [200*khalf, +200) as 7 chunks of 32 slots (24 of the last are zero
-      // padding) x its 6 row tiles; tile (g,t) holds patch elements m = 64g + 4*row + t so one aligned dword of the
-      // frame per position feeds the wave's two t.
+      // uint8 frame -> bf16 image [84][252] over Y (a byte is exact in bf16): every thread takes its pieces into
+      // registers, then -- once all have -- writes them back twice as wide
+      u32x4 raw[FR_V];
+#pragma unroll
+      for (int k = 0; k < FR_V; ++k) raw[k] = *reinterpret_cast<const u32x4*>(yp + 16 * min(tid + 256 * k, FR_CHUNKS - 1));
+      WG_BARRIER();   // [S2a] FR is in registers
+#pragma unroll
+      for (int k = 0; k < FR_V; ++k) {
+        const int c = tid + 256 * k;
+        if (c < FR_CHUNKS) {
+          u32x4 o[2];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t w = raw[k][d];
+            const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu),
+                        f3 = (float)(w >> 24);
+            o[d >> 1][2 * (d & 1)] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+            o[d >> 1][2 * (d & 1) + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+          }
+          *reinterpret_cast<u32x4*>(yp + 32 * c) = o[0];
+          *reinterpret_cast<u32x4*>(yp + 32 * c + 16) = o[1];
+        }
+      }
+      WG_BARRIER();   // [S2b] bf16 frame image complete
+      // (3) conv1 wgrad: A = pixels (one exact bf16 term), B = the three d1 planes; BOTH through transposed reads
+      // (K = position).  Wave gw: positions [200*khalf, +200) as 7 chunks of 32 slots (24 of the last are zero
+      // padding) x its 6 row tiles.
       const int pbase = 200 * khalf;
-#pragma unroll 1
+#pragma unroll BWD_UNROLL_KC
       for (int kc = 0; kc < 7; ++kc) {
+        const int s0 = 32 * kc + kdeal(q, qq) + zero, s1 = s0 + 8;
         bf16x8 bpl[3];
         {
-          const int s0 = 32 * kc + 8 * q + qq, s1 = s0 + 4;
-          const unsigned char* b0 = s0 < 200 ? xp + (pbase + s0) * XROW + 8 * pp : xzero + 8 * pp;
-          const unsigned char* b1 = s1 < 200 ? xp + (pbase + s1) * XROW + 8 * pp : xzero + 8 * pp;
+          const unsigned char* b0 = s0 < 200 ? xp + xrow(pbase + s0) * XROW + 8 * pp : xzero + 8 * pp;
+          const unsigned char* b1 = s1 < 200 ? xp + xrow(pbase + s1) * XROW + 8 * pp : xzero + 8 * pp;
           const int po0 = s0 < 200 ? XPL : 0, po1 = s1 < 200 ? XPL : 0;
 #pragma unroll
           for (int t = 0; t < 3; ++t) bpl[t] = tr_pair(b0 + t * po0, b1 + t * po1);
         }
-        int pofs[8];
+        const int ps0 = pbase + min(s0, 199), ps1 = pbase + min(s1, 199);   // padding slots: any valid address (B = 0)
+        const unsigned char* a0 = yp + (4 * (ps0 / 20) * FRAME_ROW_BYTES + 12 * (ps0 % 20)) * 2;
+        const unsigned char* a1 = yp + (4 * (ps1 / 20) * FRAME_ROW_BYTES + 12 * (ps1 % 20)) * 2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ps = pbase + min(32 * kc + 8 * q + j, 199);       // padding slots: any valid address (B = 0)
-          pofs[j] = (4 * (ps / 20)) * FRAME_ROW_BYTES + 12 * (ps % 20);
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          uint32_t w[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const uint32_t*>(fr + pofs[j] + off1[g]) >> (16 * tset);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            u32x4 pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float f0 = (float)((w[2 * e] >> (8 * t)) & 0xffu);
-              const float f1 = (float)((w[2 * e + 1] >> (8 * t)) & 0xffu);
-              pk[e] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
-            }
-            const bf16x8 av = __builtin_bit_cast(bf16x8, pk);
-            aw1[g][t] = MFMA_BF16(av, bpl[2], aw1[g][t]);
-            aw1[g][t] = MFMA_BF16(av, bpl[1], aw1[g][t]);
-            aw1[g][t] = MFMA_BF16(av, bpl[0], aw1[g][t]);
-          }
+        for (int u = 0; u < 6; ++u) {
+          const bf16x8 av = tr_pair(a0 + toff[u], a1 + toff[u]);
+          aw1[u] = MFMA_BF16(av, bpl[2], aw1[u]);
+          aw1[u] = MFMA_BF16(av, bpl[1], aw1[u]);
+          aw1[u] = MFMA_BF16(av, bpl[0], aw1[u]);
         }
       }
     }
-    if (has_next) stage_d2_planes(zp, tid, pd2, adb2);
-    __syncthreads();  // [S3] phase (3) finished reading the d1 planes and the frame
+    WG_BARRIER();     // [S3] phase (3) finished reading the d1 planes and the frame image
     if (has_next) {
       stage_c1_planes(xp, tid, pc1);
-      frame_store(fr, tid, pfr);
+      stage_d2_planes(zp, tid, pd2, adb2);
     }
   }
 
@@ -589,12 +664,9 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
       for (int r = 0; r < 4; ++r)
         atomicAdd(dW2 + ((gw * 4 + kx) * 16 + 4 * q + r) * 32 + nt * 16 + i, aw2[kx][nt][r]);
 #pragma unroll
-  for (int g = 0; g < 3; ++g)
+  for (int u = 0; u < 6; ++u)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(dW1 + (64 * g + 4 * (4 * q + r) + 2 * tset + t) * 16 + i, scale * aw1[g][t][r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * (6 * tset + u) + 4 * q + r) * 16 + i, scale * aw1[u][r]);
   // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
