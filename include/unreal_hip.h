@@ -98,7 +98,8 @@ int unreal_rollout_advance(int B, const int* terminal_t, int* active, int* activ
                            int* terminal_end, void* stream);
 int unreal_seq_mask(int B, int T, const int* seq_len, int* mask, void* stream);
 int unreal_reset_state(int B, const int* terminal_end, float* c, float* h, void* stream);
-int unreal_ring_cur_idx(int B, int H1, const int* count, int* out /*[B]*/, void* stream);
+/* out[b] = (b0 + b) * H1 + count[b] % H1: with `count` pointing at actor b0 of a larger ring, indices into THAT ring */
+int unreal_ring_cur_idx(int B, int H1, int b0, const int* count, int* out /*[B]*/, void* stream);
 int unreal_seq_last_idx(int B, const int* seq_idx, const int* seq_len, int* out /*[B]*/, void* stream);
 /* stats[3] (double) += {env steps, finished episodes, sum of their scores}; clears score_valid
  * (train/trainer.py:635-636 return value) */

@@ -358,19 +358,21 @@ def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_fr
         global_t += steps_dev
 
 
-def test_hostfed_lab_contract_matches_oracle():
+@pytest.mark.parametrize("B", [3, 4])       # 4: two half-batches alternate between host and device (overlap_host)
+def test_hostfed_lab_contract_matches_oracle(B):
     """SURVEY 8f-1 / BASELINE config 4: host simulators (synthetic stand-in for DeepMind Lab: uint8 frames, A = 6,
     sparse rewards incl. values > 1, fixed-length episodes) -> pinned staging -> HBM ring -> the same batched
     learner, against the oracle running the Lab wrapper contract (lab_environment.py:78-119) with the upstream
     replay semantics (experience_lab_ver.py) actor by actor.  Parity unpinned by the reference (no Lab fixtures)."""
     from oracle.hostfed import OracleLabEnv
     from unreal_amd.environment.synthetic_sim import SyntheticBatchSimulator, SyntheticActorSim
-    B, H, T = 3, 40, 20
+    H, T = 40, 20
     cfg = _cfg(True, True, H, T)
     cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
     kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
     sim = SyntheticBatchSimulator(B, seed=4, **kw)
     net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0)
+    assert tr.overlap_host == (B % 2 == 0)
     params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
     edraws = [ExplicitDraws() for _ in range(B)]
     envs = [OracleLabEnv(SyntheticActorSim(4 * 100003 + b, **kw), 6) for b in range(B)]
@@ -381,7 +383,8 @@ def test_hostfed_lab_contract_matches_oracle():
     assert float(tr.ring.r_reward.abs().max()) <= 1.0
 
 
-def test_hostfed_indoor_objective_matches_oracle():
+@pytest.mark.parametrize("B", [3, 4])
+def test_hostfed_indoor_objective_matches_oracle(B):
     """SURVEY 8f-4 / BASELINE config 5: the multimodal MINOS contract (indoor_environment.py:63-139): A = 3, every
     observation carries a measurement vector ('objective') that is stored beside the frame and concatenated into the
     LSTM input (experience.py:42-44, model.py:144,343; the bootstrap value gets the PREVIOUS state's objective,
@@ -390,7 +393,7 @@ def test_hostfed_indoor_objective_matches_oracle():
     from oracle.hostfed import OracleIndoorEnv
     from unreal_amd.environment.environment import Environment
     from unreal_amd.environment.synthetic_sim import SyntheticBatchIndoorSimulator, SyntheticIndoorSim
-    B, H, T, OBJ = 3, 40, 20, 5
+    H, T, OBJ = 40, 20, 5
     cfg = _cfg(True, True, H, T)
     cfg.update(action_size=3, objective_size=OBJ, initial_learning_rate=7.0711e-4)
     kw = dict(episode_len=23, reward_p=0.15, big_reward_p=0.05, objective_size=OBJ, termination_time=50.0)

@@ -41,8 +41,9 @@ class PoolSimulator(object):
 
     def step(self, actions, active=None):
         self.k += 1
-        self.t += 1
-        term = (self.t >= self.episode_len).astype(np.int32)
+        live = np.ones(self.B, bool) if active is None else (np.asarray(active) != 0)
+        self.t[live] += 1
+        term = ((self.t >= self.episode_len) & live).astype(np.int32)
         self.t[term != 0] = 0
         return self._out(self.pool[self.k % len(self.pool)], self.rew[self.k % len(self.rew)], term)
 
@@ -54,6 +55,7 @@ def main():
     ap.add_argument("--history", type=int, default=200)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--objective", type=int, default=5)
+    ap.add_argument("--no-overlap", action="store_true", help="lock-step host / device phases (round-1 behaviour)")
     args = ap.parse_args()
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
@@ -77,7 +79,7 @@ def main():
     tr = Trainer(0, net, log_uniform(flags.initial_alpha_low, flags.initial_alpha_high, flags.initial_alpha_log_rate),
                  None, applier, args.env, name, True, True, True, True, flags.pixel_change_lambda, flags.entropy_beta,
                  flags.local_t_max, flags.n_step_TD, flags.gamma, flags.gamma_pc, args.history, flags.max_time_step, dev,
-                 batch_size=args.actors, simulator=sim)
+                 batch_size=args.actors, simulator=sim, overlap_host=False if args.no_overlap else None)
     tr.prepare()
     t0 = time.time()
     while not tr._full:
@@ -104,7 +106,7 @@ def main():
         total += steps
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(json.dumps({"env": args.env, "actors": B, "action_size": A, "objective_size": obj, "history": args.history,
+    print(json.dumps({"env": args.env, "actors": B, "overlap_host": bool(tr.overlap_host), "action_size": A, "objective_size": obj, "history": args.history,
                       "replay_fill_s": round(fill_s, 2), "ingest_only_env_steps_per_s": round(ingest),
                       "process_env_steps_per_s": round(total / dt), "ms_per_process": round(1e3 * dt / args.steps, 2),
                       "pcie_bytes_per_env_step": 21168 + 8 + 4 * obj + 4,

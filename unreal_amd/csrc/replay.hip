@@ -207,9 +207,9 @@ __global__ void reset_state_kernel(int B, const int* terminal_end, float* c, flo
 }
 
 // frame index of every actor's current observation: b*H1 + count[b] % H1
-__global__ void ring_cur_idx_kernel(int B, int H1, const int* count, int* out) {
+__global__ void ring_cur_idx_kernel(int B, int H1, int b0, const int* count, int* out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) out[b] = b * H1 + count[b] % H1;
+  if (b < B) out[b] = (b0 + b) * H1 + count[b] % H1;
 }
 
 // bootstrap frame of every sampled sequence: the LAST sampled frame (trainer.py:356-358, 396-398)
@@ -326,9 +326,9 @@ int unreal_seq_mask(int B, int T, const int* seq_len, int* mask, void* stream) {
   return unreal_launch_status();
 }
 
-int unreal_ring_cur_idx(int B, int H1, const int* count, int* out, void* stream) {
+int unreal_ring_cur_idx(int B, int H1, int b0, const int* count, int* out, void* stream) {
   if (B <= 0 || H1 < 2 || !count || !out) return UNREAL_EINVAL;
-  hipLaunchKernelGGL(ring_cur_idx_kernel, GRID1(B), B, H1, count, out);
+  hipLaunchKernelGGL(ring_cur_idx_kernel, GRID1(B), B, H1, b0, count, out);
   return unreal_launch_status();
 }
 

@@ -93,5 +93,77 @@ class HostFedEnvironment(object):
             self._stage_objective(out[3], active)
         self._mark_staging()
 
+    # ---- half-batch interface: host phase of one part overlaps the device phase of the other ---------
+    def enable_parts(self, n_parts=2):
+        """Split the actors into `n_parts` contiguous parts, each with its own HIP stream, pinned staging and ring view,
+        so that the Trainer can alternate: while the host simulates / stages part k, the device ingests and forwards the
+        other part.  Returns the part boundaries [(b0, b1), ...]."""
+        if self.B % n_parts:
+            raise ValueError("%d actors do not split into %d parts" % (self.B, n_parts))
+        Bp = self.B // n_parts
+        self.parts = []
+        for k in range(n_parts):
+            b0, b1 = k * Bp, (k + 1) * Bp
+            part = dict(b0=b0, b1=b1, ring=ops.ring_view(self.ring, b0, b1), stream=torch.cuda.Stream(device=self.device),
+                        h_frames=torch.empty((Bp, 84, 84, 3), dtype=torch.uint8).pin_memory(),
+                        h_rewards=torch.empty(Bp, dtype=torch.float32).pin_memory(),
+                        h_terminals=torch.empty(Bp, dtype=torch.int32).pin_memory(),
+                        h_actions=torch.empty(Bp, dtype=torch.int32).pin_memory(),
+                        h_active=torch.empty(Bp, dtype=torch.int32).pin_memory(),
+                        staged=self._staged[b0 * ops.FRAME_BYTES:b1 * ops.FRAME_BYTES],
+                        rewards=self._rewards[b0:b1], terminals=self._terminals[b0:b1], h2d_done=None,
+                        act_ready=torch.cuda.Event())
+            if self.objective_size:
+                part["h_obj"] = torch.empty((Bp, self.objective_size), dtype=torch.float32).pin_memory()
+                part["obj"] = self._obj[b0 * self.objective_size:b1 * self.objective_size]
+            self.parts.append(part)
+        self._act_full = np.zeros(self.B, np.int32)
+        self._mask_full = np.zeros(self.B, np.int32)
+        return [(p["b0"], p["b1"]) for p in self.parts]
+
+    def part_request_actions(self, k, actions, active):
+        """On part k's stream: start the D2H copy of its drawn actions (and active flags) into pinned memory."""
+        p = self.parts[k]
+        p["h_actions"].copy_(actions, non_blocking=True)
+        if active is not None:
+            p["h_active"].copy_(active, non_blocking=True)
+        p["act_ready"].record()
+
+    def part_host_step(self, k, has_active):
+        """Host phase of part k: wait for its actions, step ITS simulators only, fill its pinned staging."""
+        p = self.parts[k]
+        p["act_ready"].synchronize()
+        if p["h2d_done"] is not None:
+            p["h2d_done"].synchronize()                # the previous H2D copies out of this staging have finished
+        b0, b1 = p["b0"], p["b1"]
+        self._act_full[b0:b1] = p["h_actions"].numpy()
+        self._mask_full[:] = 0
+        self._mask_full[b0:b1] = p["h_active"].numpy() if has_active else 1
+        out = self.sim.step(self._act_full, self._mask_full)
+        frames, rewards, terminals = out[:3]
+        rewards = rewards[b0:b1]
+        if self.reward_divisor != 1.0:                  # indoor_environment.py:111
+            rewards = (rewards.astype(np.float64) / self.reward_divisor).astype(np.float32)
+        p["h_frames"].copy_(torch.from_numpy(np.ascontiguousarray(frames[b0:b1])))
+        p["h_rewards"].copy_(torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32)))
+        p["h_terminals"].copy_(torch.from_numpy(np.ascontiguousarray(terminals[b0:b1], dtype=np.int32)))
+        if self.objective_size:
+            p["h_obj"].copy_(torch.from_numpy(np.ascontiguousarray(out[3][b0:b1], dtype=np.float32)))
+
+    def part_ingest(self, k, actions, active, out_reward, out_terminal, reset_on_terminal=True, track_score=False):
+        """On part k's stream: H2D of the staged part + the ring commit kernel for its actors."""
+        p = self.parts[k]
+        p["staged"].copy_(p["h_frames"].view(-1), non_blocking=True)
+        p["rewards"].copy_(p["h_rewards"], non_blocking=True)
+        p["terminals"].copy_(p["h_terminals"], non_blocking=True)
+        ops.hostfed_step(p["ring"], p["staged"], actions, p["rewards"], p["terminals"], active, out_reward, out_terminal,
+                         reset_on_terminal, track_score, self.clip_reward, self.pc_denom)
+        if self.objective_size:
+            p["obj"].copy_(p["h_obj"].view(-1), non_blocking=True)
+            ops.objective_put(p["ring"], p["obj"], active)
+        if p["h2d_done"] is None:
+            p["h2d_done"] = torch.cuda.Event()
+        p["h2d_done"].record()
+
     def stop(self):
         pass

@@ -267,7 +267,7 @@ class UnrealModel(object):
 
     # -- batched building blocks -----------------------------------------------------------------------
     def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
-                    objective_slot_offset=0):
+                    objective_slot_offset=0, actor_ring=None):
         """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
         rows [row0, row0+nrows) of a path workspace.  `objective_slot_offset` = -1 reproduces trainer.py:300, where the
         bootstrap value is fed the objective of the previous frame's state."""
@@ -287,19 +287,22 @@ class UnrealModel(object):
         if lar_from_ring:
             ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, self.xld)
         else:
-            ops.lar_fill(nrows, A, ring.last_action, ring.last_reward, None, xcat, self.xld, clip=clip_lar)
+            ar = ring if actor_ring is None else actor_ring     # per-actor state of a sub-range of the ring's actors
+            ops.lar_fill(nrows, A, ar.last_action, ar.last_reward, None, xcat, self.xld, clip=clip_lar)
         if self._objective_size:
             ops.objective_fill(ring, nrows, idx, xcat, self.xld, 256 + A + 1, slot_offset=objective_slot_offset)
         ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
 
-    def lstm_step(self, ws, t, B):
-        """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math)."""
+    def lstm_step(self, ws, t, B, b0=0, nrows=None):
+        """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math); `b0`, `nrows`: only the
+        actors [b0, b0 + nrows) of the block."""
         p = self.p
-        h_prev = ws.h0 if t == 0 else ws.h[(t - 1) * B * 256:]
-        c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
-        g_t = ws.gates[t * B * 1024:]
-        ops.lstm_step_fwd(B, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[t * B * 256:],
-                          ws.h[t * B * 256:])
+        n = B if nrows is None else nrows
+        h_prev = ws.h0[b0 * 256:] if t == 0 else ws.h[((t - 1) * B + b0) * 256:]
+        c_prev = ws.c0[b0 * 256:] if t == 0 else ws.c[((t - 1) * B + b0) * 256:]
+        g_t = ws.gates[(t * B + b0) * 1024:]
+        ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[(t * B + b0) * 256:],
+                          ws.h[(t * B + b0) * 256:])
 
     def features(self, ws, row0=0):
         """(tensor, ld) of the features the heads read: LSTM outputs, or the fc output in FF mode."""

@@ -89,11 +89,12 @@ class Ring(object):
 
         self._cur = z(B, dt=torch.int32)
 
-    def cur_idx(self, out=None):
-        """Frame index of every actor's current observation (slot count % H1)."""
+    def cur_idx(self, out=None, base_actor=0):
+        """Frame index of every actor's current observation (slot count % H1).  `base_actor` = index of this (view's)
+        first actor in the ring the indices are meant for: a view then yields indices into its parent ring."""
         out = self._cur if out is None else out
         _chk(out, "i32", self.B, "cur_idx out")
-        _call("unreal_ring_cur_idx", self.B, self.H1, ptr(self.count), ptr(out))
+        _call("unreal_ring_cur_idx", self.B, self.H1, int(base_actor), ptr(self.count), ptr(out))
         return out
 
 

@@ -75,11 +75,14 @@ class Trainer(object):
                  experience_history_size, max_global_time_step, device, segnet_param_dict=None,
                  image_shape=(84, 84), is_training=True, n_classes=0, random_state=None, termination_time=50.0,
                  segnet_lambda=1.0, dropout=0.0, batch_size=1, world_size=1, rank=0, seed=0xA3C, draws=None,
-                 grad_sync=None, simulator=None, groups=1):
+                 grad_sync=None, simulator=None, groups=1, overlap_host=None):
         if env_type != "maze" and simulator is None:
             raise NotImplementedError("env_type=%r needs a host simulator object (simulator=...); only 'maze' runs "
                                       "entirely on the device" % env_type)
         self.simulator = simulator
+        # host-fed actors: alternate two half-batches between the host (simulators, staging) and the device (None = on
+        # whenever the batch splits in two)
+        self._overlap_request = overlap_host
         # upstream replay semantics for host-fed (Lab-contract) actors: zero / non-zero reward buckets and reward
         # clipping (train/experience_lab_ver.py:14,18,76-80); this fork's buckets for the maze (train/experience.py)
         self.rp_mode = 1 if env_type == "lab" else 0      # indoor: this fork's train/experience.py, like the maze
@@ -142,6 +145,12 @@ class Trainer(object):
                                                   action_size=A, clip_reward=not indoor,
                                                   objective_size=self.objective_size,
                                                   reward_divisor=termination_time if indoor else 1.0)
+        self.overlap_host = False
+        if self.env_type != "maze":
+            want = self._overlap_request if self._overlap_request is not None else (B % 2 == 0 and B >= 2)
+            if want:
+                self.environment.enable_parts(2)
+                self.overlap_host = True
         self.full_environment = self.environment
         self.full_ring = self.ring = self.environment.ring
         self.local_network.bind_frame_scale(self.environment.frame_scale)
@@ -255,6 +264,51 @@ class Trainer(object):
             ops.copy_(self.lstm_c, ws.c[:B * 256])
             ops.copy_(self.lstm_h, ws.h[:B * 256])
 
+    def _rollout_steps_overlapped(self):
+        """The T rollout steps for host-fed actors in two half-batches: while the host steps / stages one half (its
+        simulators live on the CPU), the device ingests and forwards the other half on that half's own stream.  Same
+        kernels, same rows, same draws as the lock-step loop -- only the schedule differs."""
+        B, T, A, ws, net = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network
+        env = self.environment
+        parts = env.parts
+        main = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(main)
+
+        def forward(k, t):          # on part k's stream: policy forward of its actors for step t + action D2H request
+            p = parts[k]
+            b0, n = p["b0"], p["b1"] - p["b0"]
+            r0 = t * B + b0
+            p["ring"].cur_idx(out=ws.frame_idx[r0:r0 + n], base_actor=b0)
+            net.encode_rows(self.ring, ws, r0, n, lar_from_ring=False, save_c1=ws.c1 is not None, actor_ring=p["ring"])
+            if self.use_lstm:
+                net.lstm_step(ws, t, B, b0, n)
+            feat, ld = net.features(ws, r0)
+            net.policy_step(n, feat, ld, self.u_act[r0:r0 + n], self.pi[r0 * A:(r0 + n) * A], self.v[r0:r0 + n],
+                            self.actions[r0:r0 + n])
+            env.part_request_actions(k, self.actions[r0:r0 + n], self.active[b0:b0 + n])
+
+        for k, p in enumerate(parts):
+            with torch.cuda.stream(p["stream"]):
+                p["stream"].wait_event(start)
+                forward(k, 0)
+        for t in range(T):
+            for k, p in enumerate(parts):
+                b0, n = p["b0"], p["b1"] - p["b0"]
+                r0 = t * B + b0
+                env.part_host_step(k, has_active=True)           # host: the other part's device work runs meanwhile
+                with torch.cuda.stream(p["stream"]):
+                    env.part_ingest(k, self.actions[r0:r0 + n], self.active[b0:b0 + n], self.rewards[r0:r0 + n],
+                                    self.terminals[r0:r0 + n], reset_on_terminal=True, track_score=True)
+                    ops.rollout_advance(n, self.terminals[r0:r0 + n], self.active[b0:b0 + n],
+                                        self.active_log[r0:r0 + n], self.n_steps[b0:b0 + n], self.terminal_end[b0:b0 + n])
+                    if t + 1 < T:
+                        forward(k, t + 1)
+        for p in parts:                                          # join: the learner continues on the caller's stream
+            done = torch.cuda.Event()
+            done.record(p["stream"])
+            main.wait_event(done)
+
     def _rollout(self):
         """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
         B, T, A, ws, net = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network
@@ -265,7 +319,9 @@ class Trainer(object):
         self.n_steps.zero_()
         self.terminal_end.zero_()
         self.draws.uniform(self.u_act)
-        for t in range(T):
+        if self.overlap_host:
+            self._rollout_steps_overlapped()
+        for t in range(0 if not self.overlap_host else T, T):
             s = slice(t * B, (t + 1) * B)
             self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s])
             self.environment.process(self.actions[s], self.active, self.rewards[s], self.terminals[s],
