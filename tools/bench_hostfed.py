@@ -23,13 +23,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 class PoolSimulator(object):
     """Batched host simulator that costs (almost) nothing: frames come from a pre-generated pool."""
 
-    def __init__(self, batch, objective_size=0, episode_len=900, pool=4, seed=4):
+    def __init__(self, batch, objective_size=0, episode_len=900, pool=4, seed=4, ms_per_step=0.0):
         rs = np.random.RandomState(seed)
         self.B, self.objective_size, self.episode_len = batch, objective_size, episode_len
         self.pool = [rs.randint(0, 256, size=(batch, 84, 84, 3)).astype(np.uint8) for _ in range(pool)]
         self.obj = [rs.uniform(-1, 1, size=(batch, max(objective_size, 1))).astype(np.float32) for _ in range(pool)]
         self.rew = [(rs.random_sample(batch) < 0.01).astype(np.float32) for _ in range(pool)]
         self.t, self.k = np.zeros(batch, np.int64), 0
+        self.ms_per_step = ms_per_step          # modelled cost of stepping ALL actors once (worker processes: the host
+                                                # thread just waits), scaled by the share of actors a call steps
 
     def _out(self, frames, *rest):
         return (frames,) + rest + ((self.obj[self.k % len(self.obj)][:, :self.objective_size],) if self.objective_size else ())
@@ -42,6 +44,8 @@ class PoolSimulator(object):
     def step(self, actions, active=None):
         self.k += 1
         live = np.ones(self.B, bool) if active is None else (np.asarray(active) != 0)
+        if self.ms_per_step > 0:
+            time.sleep(1e-3 * self.ms_per_step * float(live.sum()) / self.B)
         self.t[live] += 1
         term = ((self.t >= self.episode_len) & live).astype(np.int32)
         self.t[term != 0] = 0
@@ -56,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--objective", type=int, default=5)
     ap.add_argument("--no-overlap", action="store_true", help="lock-step host / device phases (round-1 behaviour)")
+    ap.add_argument("--sim-ms", type=float, default=0.0, help="modelled simulator time per step of the whole batch (ms)")
     args = ap.parse_args()
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
@@ -75,7 +80,7 @@ def main():
                       frame_scale=1.0 / 255.0)
     applier = RMSPropApplier(None, decay=flags.rmsp_alpha, momentum=0.0, epsilon=flags.rmsp_epsilon,
                              clip_norm=flags.grad_norm_clip, device=dev)
-    sim = PoolSimulator(args.actors, objective_size=obj)
+    sim = PoolSimulator(args.actors, objective_size=obj, ms_per_step=args.sim_ms)
     tr = Trainer(0, net, log_uniform(flags.initial_alpha_low, flags.initial_alpha_high, flags.initial_alpha_log_rate),
                  None, applier, args.env, name, True, True, True, True, flags.pixel_change_lambda, flags.entropy_beta,
                  flags.local_t_max, flags.n_step_TD, flags.gamma, flags.gamma_pc, args.history, flags.max_time_step, dev,
@@ -106,7 +111,7 @@ def main():
         total += steps
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(json.dumps({"env": args.env, "actors": B, "overlap_host": bool(tr.overlap_host), "action_size": A, "objective_size": obj, "history": args.history,
+    print(json.dumps({"env": args.env, "actors": B, "overlap_host": bool(tr.overlap_host), "sim_ms_per_step": args.sim_ms, "action_size": A, "objective_size": obj, "history": args.history,
                       "replay_fill_s": round(fill_s, 2), "ingest_only_env_steps_per_s": round(ingest),
                       "process_env_steps_per_s": round(total / dt), "ms_per_process": round(1e3 * dt / args.steps, 2),
                       "pcie_bytes_per_env_step": 21168 + 8 + 4 * obj + 4,

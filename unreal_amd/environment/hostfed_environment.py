@@ -10,10 +10,31 @@ With objective_size > 0 it is the MINOS wrapper contract of /root/reference/envi
 instead: the simulator also returns a measurement vector per actor (reset -> (frames, objectives),
 step -> (frames, rewards, terminals, objectives)), stored beside the frame in the ring and concatenated into the LSTM
 input; rewards are divided by termination_time (:111) and not clipped."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
 import torch
 
 from .. import ops
+
+# The simulators' frames reach the pinned staging by a host memcpy of 21 KB per actor and step -- the largest host
+# cost of the path.  It is cut into row blocks copied by a few threads (torch's copy releases the GIL).
+_COPY_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))
+_COPY_POOL = ThreadPoolExecutor(_COPY_THREADS) if _COPY_THREADS > 1 else None
+
+
+def _stage_frames(dst, frames):
+    """dst (pinned uint8 [n,84,84,3]) <- frames (numpy uint8 [n,84,84,3]), in parallel row blocks."""
+    src = torch.from_numpy(np.ascontiguousarray(frames))
+    n = dst.shape[0]
+    if _COPY_POOL is None or n < 4 * _COPY_THREADS:
+        dst.copy_(src)
+        return
+    step = (n + _COPY_THREADS - 1) // _COPY_THREADS
+    futs = [_COPY_POOL.submit(dst[a:a + step].copy_, src[a:a + step]) for a in range(0, n, step)]
+    for f in futs:
+        f.result()
 
 
 class HostFedEnvironment(object):
@@ -54,7 +75,7 @@ class HostFedEnvironment(object):
         self._h2d_done.record()
 
     def _stage(self, frames):
-        self._h_frames.copy_(torch.from_numpy(np.ascontiguousarray(frames)))
+        _stage_frames(self._h_frames, frames)
         self._staged.copy_(self._h_frames.view(-1), non_blocking=True)
 
     def _stage_objective(self, objectives, active):
@@ -144,7 +165,7 @@ class HostFedEnvironment(object):
         rewards = rewards[b0:b1]
         if self.reward_divisor != 1.0:                  # indoor_environment.py:111
             rewards = (rewards.astype(np.float64) / self.reward_divisor).astype(np.float32)
-        p["h_frames"].copy_(torch.from_numpy(np.ascontiguousarray(frames[b0:b1])))
+        _stage_frames(p["h_frames"], frames[b0:b1])
         p["h_rewards"].copy_(torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32)))
         p["h_terminals"].copy_(torch.from_numpy(np.ascontiguousarray(terminals[b0:b1], dtype=np.int32)))
         if self.objective_size:
