@@ -41,7 +41,7 @@ def _cfg(use_lstm, aux, H, T):
                 initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
 
 
-def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=None, env_name="", groups=1):
+def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=None, env_name="", groups=1, overlap_host=None):
     from unreal_amd.environment.environment import Environment
     from unreal_amd.model.model import UnrealModel
     from unreal_amd.train.rmsprop_applier import RMSPropApplier
@@ -59,7 +59,7 @@ def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=None, env_
                  cfg["use_value_replay"], cfg["use_reward_prediction"], cfg["pixel_change_lambda"],
                  cfg["entropy_beta"], cfg["local_t_max"], cfg["n_step_TD"], cfg["gamma"], cfg["gamma_pc"],
                  cfg["experience_history_size"], cfg["max_time_step"], DEV, batch_size=B, draws=draws,
-                 simulator=simulator, groups=groups)
+                 simulator=simulator, groups=groups, overlap_host=overlap_host)
     tr.prepare()
     return net, applier, tr, draws
 
@@ -371,7 +371,8 @@ def test_hostfed_lab_contract_matches_oracle(B):
     cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
     kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
     sim = SyntheticBatchSimulator(B, seed=4, **kw)
-    net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0)
+    net, applier, tr, draws = _build(cfg, B, seed=9, env_type="lab", simulator=sim, frame_scale=1.0 / 255.0,
+                                     overlap_host=(B % 2 == 0))
     assert tr.overlap_host == (B % 2 == 0)
     params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
     edraws = [ExplicitDraws() for _ in range(B)]
@@ -400,7 +401,7 @@ def test_hostfed_indoor_objective_matches_oracle(B):
     Environment.register_indoor_config("synthetic_rooms", OBJ)
     sim = SyntheticBatchIndoorSimulator(B, seed=5, **kw)
     net, applier, tr, draws = _build(cfg, B, seed=11, env_type="indoor", env_name="synthetic_rooms", simulator=sim,
-                                     frame_scale=1.0 / 255.0)
+                                     frame_scale=1.0 / 255.0, overlap_host=(B % 2 == 0))
     assert net.K_x == 256 + 3 + 1 + OBJ and net.params.shaped("lstm_kernel").shape == (net.K_x + 256, 1024)
     params = {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
     edraws = [ExplicitDraws() for _ in range(B)]

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--objective", type=int, default=5)
     ap.add_argument("--no-overlap", action="store_true", help="lock-step host / device phases (round-1 behaviour)")
+    ap.add_argument("--overlap", action="store_true", help="force the two-half-batch schedule (default: from 2048 actors)")
     ap.add_argument("--sim-ms", type=float, default=0.0, help="modelled simulator time per step of the whole batch (ms)")
     args = ap.parse_args()
     from unreal_amd.environment.environment import Environment
@@ -84,7 +85,7 @@ def main():
     tr = Trainer(0, net, log_uniform(flags.initial_alpha_low, flags.initial_alpha_high, flags.initial_alpha_log_rate),
                  None, applier, args.env, name, True, True, True, True, flags.pixel_change_lambda, flags.entropy_beta,
                  flags.local_t_max, flags.n_step_TD, flags.gamma, flags.gamma_pc, args.history, flags.max_time_step, dev,
-                 batch_size=args.actors, simulator=sim, overlap_host=False if args.no_overlap else None)
+                 batch_size=args.actors, simulator=sim, overlap_host=False if args.no_overlap else (True if args.overlap else None))
     tr.prepare()
     t0 = time.time()
     while not tr._full:

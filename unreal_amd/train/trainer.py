@@ -80,8 +80,10 @@ class Trainer(object):
             raise NotImplementedError("env_type=%r needs a host simulator object (simulator=...); only 'maze' runs "
                                       "entirely on the device" % env_type)
         self.simulator = simulator
-        # host-fed actors: alternate two half-batches between the host (simulators, staging) and the device (None = on
-        # whenever the batch splits in two)
+        # host-fed actors: alternate two half-batches between the host (simulators, staging) and the device.  None = on
+        # from 2048 actors: measured with a cost-free simulator the halves win 1.22x at 4096 actors (654 k vs 537 k
+        # env-steps/s) and lose 0.85x at 1024 (the device phase of a step is then too short to be worth twice the
+        # launches); with a simulator that dominates the step the two schedules are within 5 %
         self._overlap_request = overlap_host
         # upstream replay semantics for host-fed (Lab-contract) actors: zero / non-zero reward buckets and reward
         # clipping (train/experience_lab_ver.py:14,18,76-80); this fork's buckets for the maze (train/experience.py)
@@ -147,7 +149,7 @@ class Trainer(object):
                                                   reward_divisor=termination_time if indoor else 1.0)
         self.overlap_host = False
         if self.env_type != "maze":
-            want = self._overlap_request if self._overlap_request is not None else (B % 2 == 0 and B >= 2)
+            want = self._overlap_request if self._overlap_request is not None else (B % 2 == 0 and B >= 2048)
             if want:
                 self.environment.enable_parts(2)
                 self.overlap_host = True
