@@ -392,7 +392,7 @@ def _enc_params(seed):
     return p
 
 
-@pytest.mark.parametrize("N,mode", [(1, "maze"), (5, "u8"), (67, "u8"), (600, "maze")])
+@pytest.mark.parametrize("N,mode", [(1, "maze"), (5, "u8"), (67, "u8"), (600, "maze"), (1300, "u8")])   # > 512 workgroups: grid stride
 def test_encoder_fwd(ops, N, mode):
     rs = np.random.RandomState(N)
     p = _enc_params(1)

@@ -20,39 +20,8 @@
 namespace {
 
 constexpr int FR_LDS = 21184;            // FRAME_BYTES rounded up to 64
-constexpr int C1_LD = 20;                // floats per conv1 position in LDS
-constexpr int C1_LDS = C1_POS * C1_LD;   // 8000 floats
-constexpr int W2_ELEMS = 256 * 32;
-constexpr int D2_LD = 36;
-constexpr int D2_ROWS = 84;              // 81 + 3 zero rows (row 81 doubles as the "padding" row)
-constexpr int F2S = C2_POS * C2_CH;      // 2592 floats: conv2 output staging
 constexpr int FR_V = (FRAME_BYTES / 16 + 255) / 256;   // 16 B vectors per thread to move one frame (6)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void cvt4(uint32_t w, float (&f)[4]) {
-  f[0] = (float)(w & 0xffu);
-  f[1] = (float)((w >> 8) & 0xffu);
-  f[2] = (float)((w >> 16) & 0xffu);
-  f[3] = (float)(w >> 24);
-}
-
-__device__ __forceinline__ void frame_load(const uint8_t* __restrict__ src, int gtid, u32x4 (&r)[FR_V]) {
-  const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
-#pragma unroll
-  for (int c = 0; c < FR_V; ++c) {
-    int id = gtid + 256 * c;
-    r[c] = s4[id < FRAME_BYTES / 16 ? id : gtid];   // unconditional: keeps the array in registers
-  }
-}
-
-__device__ __forceinline__ void frame_store(uint8_t* dst, int gtid, const u32x4 (&r)[FR_V]) {
-  u32x4* d4 = reinterpret_cast<u32x4*>(dst);
-#pragma unroll
-  for (int c = 0; c < FR_V; ++c) {
-    int id = gtid + 256 * c;
-    if (id < FRAME_BYTES / 16) d4[id] = r[c];
-  }
-}
 
 // ---- conv1 forward as EXACT-PRODUCT bf16 MFMAs -----------------------------------------------------
 // The uint8 pixel is exact in bf16 (8 significant bits) and every fp32 weight is split once per kernel into
@@ -107,149 +76,8 @@ __device__ __forceinline__ bf16x8 u8x8_to_bf16(uint32_t w0, uint32_t w1) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// conv1 for TWO (or one) 16-position tiles: fr (uint8 LDS) -> c1 (fp32 LDS, post-ReLU)
-template <bool TWO>
-__device__ __forceinline__ void conv1_tile_pair(const uint8_t* fr, float* c1, const u32x4v (&wb)[6][3],
-                                                const int (&koff)[6], float bias_j, float scale, int ta, int tb, int i,
-                                                int q) {
-  const int pa = ta * 16 + i, pb = tb * 16 + i;
-  const uint8_t* fa = fr + (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
-  const uint8_t* fb = fr + (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
-  f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kc = 0; kc < 6; ++kc) {
-    const uint32_t* pa32 = reinterpret_cast<const uint32_t*>(fa + koff[kc]);
-    const bf16x8 aa = u8x8_to_bf16(pa32[0], pa32[1]);
-    bf16x8 ab;
-    if (TWO) {
-      const uint32_t* pb32 = reinterpret_cast<const uint32_t*>(fb + koff[kc]);
-      ab = u8x8_to_bf16(pb32[0], pb32[1]);
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const bf16x8 bw = __builtin_bit_cast(bf16x8, wb[kc][t]);
-      acca = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aa, bw, acca, 0, 0, 0);
-      if (TWO) accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bw, accb, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    c1[(ta * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * acca[r] + bias_j, 0.f);
-    if (TWO) c1[(tb * 16 + 4 * q + r) * C1_LD + i] = fmaxf(scale * accb[r] + bias_j, 0.f);
-  }
-}
-
-__global__ __launch_bounds__(512) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
-                                                          const int* __restrict__ frame_idx, float scale,
-                                                          const float* __restrict__ W1, const float* __restrict__ b1,
-                                                          const float* __restrict__ W2, const float* __restrict__ b2,
-                                                          float* __restrict__ c1_out, float* __restrict__ f2_out) {
-  constexpr int GRP_BYTES = FR_LDS + C1_LDS * 4 + F2S * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * GRP_BYTES + W2_ELEMS * 4];
-  const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
-  const int lane = threadIdx.x & 63, gw = gtid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  uint8_t* fr = smem + grp * GRP_BYTES;
-  float* c1 = reinterpret_cast<float*>(fr + FR_LDS);
-  float* f2s = c1 + C1_LDS;
-  float* w2s = reinterpret_cast<float*>(smem + 2 * GRP_BYTES);
-
-  // W2 -> LDS as [(ky*4+c)][q][n(32)][s]: k = ky*64 + q*16 + 4c + s
-  for (int e = threadIdx.x; e < W2_ELEMS; e += 512) {
-    int s = e & 3, n = (e >> 2) & 31, qq = (e >> 7) & 3, kc = e >> 9;
-    int k = (kc >> 2) * 64 + qq * 16 + 4 * (kc & 3) + s;
-    w2s[e] = W2[k * 32 + n];
-  }
-  u32x4v w1[6][3];
-  load_w1_bf16x3(W1, q, i, w1);
-  int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
-#pragma unroll
-  for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
-  const float bias1 = b1[i];
-  const int nt = gw & 1;                       // this wave's conv2 N-tile
-  const float bias2 = b2[nt * 16 + i];
-
-  const int stride = gridDim.x * 2;
-  u32x4 pre[FR_V];
-  {
-    const int n0 = blockIdx.x * 2 + grp;
-    if (n0 < N) {
-      frame_load(frames + (size_t)frame_idx[n0] * FRAME_BYTES, gtid, pre);
-      frame_store(fr, gtid, pre);
-    }
-  }
-  __syncthreads();
-
-  int prev = -1;                               // frame whose conv2 output still sits in f2s
-  for (int base = blockIdx.x * 2; base < N; base += stride) {
-    const int n = base + grp;
-    const bool valid = n < N;
-    // drain the previous frame's conv2 output: LDS -> HBM in full 128 B lines
-    if (prev >= 0) {
-      f32x4* dst = reinterpret_cast<f32x4*>(f2_out + (size_t)prev * F2_DIM);
-      for (int id = gtid; id < F2S / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(f2s)[id];
-    }
-    if (valid) {
-      for (int tt = gw; tt < 25; tt += 8) {
-        if (tt + 4 < 25) conv1_tile_pair<true>(fr, c1, w1, koff, bias1, scale, tt, tt + 4, i, q);
-        else conv1_tile_pair<false>(fr, c1, w1, koff, bias1, scale, tt, tt, i, q);
-      }
-    }
-    __syncthreads();  // c1 complete; fr free; f2s drained
-
-    const int nn = n + stride;
-    const bool has_next = nn < N;
-    if (has_next) frame_load(frames + (size_t)frame_idx[nn] * FRAME_BYTES, gtid, pre);
-
-    if (valid) {
-      // conv2: this wave owns M-tiles mt = (gw>>1) + 2*jj (jj = 0..2) of N-tile nt
-      f32x4 acc[3];
-      int abase[3];
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj) {
-        acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        int pos2 = min(((gw >> 1) + 2 * jj) * 16 + i, C2_POS - 1);
-        abase[jj] = ((2 * (pos2 / 9)) * 20 + 2 * (pos2 % 9) + q) * C1_LD;
-      }
-#pragma unroll
-      for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 bw = *reinterpret_cast<const f32x4*>(w2s + ((((ky * 4 + c) * 4 + q) * 32) + nt * 16 + i) * 4);
-          f32x4 av[3];
-#pragma unroll
-          for (int jj = 0; jj < 3; ++jj)
-            av[jj] = *reinterpret_cast<const f32x4*>(c1 + abase[jj] + ky * 20 * C1_LD + 4 * c);
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) acc[jj] = MFMA16(av[jj][s], bw[s], acc[jj]);
-        }
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int pos2 = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
-          if (pos2 < C2_POS) f2s[pos2 * 32 + nt * 16 + i] = fmaxf(acc[jj][r] + bias2, 0.f);
-        }
-      if (c1_out) {
-        f32x4* dst = reinterpret_cast<f32x4*>(c1_out + (size_t)n * (C1_POS * C1_CH));
-        for (int id = gtid; id < C1_POS * 4; id += 256)
-          dst[id] = *reinterpret_cast<const f32x4*>(c1 + (id >> 2) * C1_LD + (id & 3) * 4);
-      }
-    }
-    if (has_next) frame_store(fr, gtid, pre);
-    prev = valid ? n : -1;
-    __syncthreads();  // next frame staged; c1 free; f2s complete
-  }
-  if (prev >= 0) {
-    f32x4* dst = reinterpret_cast<f32x4*>(f2_out + (size_t)prev * F2_DIM);
-    for (int id = gtid; id < F2S / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(f2s)[id];
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Backward.  Input d2 = dL/d(conv2 pre-activation) [N][81][32] (ReLU mask already applied by the
+// Backward (its LDS helpers are shared with the forward kernel below).  Input d2 = dL/d(conv2 pre-activation) [N][81][32] (ReLU mask already applied by the
 // producer), c1 = saved conv1 activation [N][400][16], the uint8 frame.  Produces dW2, dW1 (register
 // accumulators across all frames of the workgroup, flushed once with float atomics), db2, db1.
 //   (1) dW2[(ky,kx,c)][n] += sum_pos c1[2oy+ky][2ox+kx][c] * d2[pos][n]            M=256 N=32 K=81
@@ -416,6 +244,187 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward: conv1 8x8 s4 + ReLU -> conv2 4x4 s2 + ReLU, fused per frame, BOTH on v_mfma_f32_16x16x32_bf16 with
+// fp32-grade error.  conv1 (above): the uint8 pixel is one exact bf16 term, the weights three -> 3 MFMAs per tile
+// and K chunk.  conv2: c1 is split into three bf16 planes as it leaves conv1's accumulators, W2 once per kernel;
+// six term-pair MFMAs per tile and K chunk (6/16 of the fp32 MFMA's matrix-pipe time, which round 1 used here).
+//
+// One frame per 256-thread workgroup at a time, two workgroups per CU (71 KB of LDS each), like the backward:
+//   FR  the uint8 frame, by LDS-DMA (issued for frame n+1 as soon as conv1 of frame n has read FR; lands under conv2)
+//   X   c1 planes [3][400 pos][16 ch] bf16 (row p stored at p ^ ((p>>3)&1), as in the backward)
+//   P   partial conv2 tiles of the waves that own the upper half of K
+// conv1 is evaluated TRANSPOSED (D[channel][position] = W1^T x patches): a lane then holds 4 consecutive channels of
+// one position, i.e. one 16-byte store of the saved fp32 activation and one 8-byte store per bf16 plane.
+// conv2: M = 81 positions (6 tiles), N = 32, K = 256 = 8 chunks of (2 taps x 16 channels).  No LDS is left for
+// W2, so its fragments live in registers and the work is cut so that a wave needs few of them: wave gw owns n-tile
+// gw & 1 and K half gw >> 1 (4 chunks: 48 registers of W2 fragments) for all 6 position tiles; the two halves of K
+// are added in a FIXED order (lower + upper) through P, so the result does not depend on scheduling.
+// ------------------------------------------------------------------------------------------------
+constexpr int FWD_FR = FR_DMA * 1024;            // 21504: uint8 frame + DMA overshoot
+constexpr int FWD_X = FWD_FR;
+constexpr int FWD_P = FWD_X + 3 * XPL;           // 59904
+constexpr int FWD_LDS = FWD_P + 2 * 6 * 1024;    // 72192
+static_assert(2 * FWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS");
+
+// conv1 for TWO (or one) 16-position tiles, transposed: acc[r] = channel 4q + r at position 16 t + i
+template <bool TWO>
+__device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp, float* __restrict__ c1_out,
+                                            const u32x4v (&w1)[6][3], const int (&koff)[6], const f32x4& bias, float scale,
+                                            int ta, int tb, int i, int q) {
+  const int pa = ta * 16 + i, pb = tb * 16 + i;
+  const uint8_t* fa = fr + (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
+  const uint8_t* fb = fr + (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
+  f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) {
+    const uint32_t* pa32 = reinterpret_cast<const uint32_t*>(fa + koff[kc]);
+    const bf16x8 xa = u8x8_to_bf16(pa32[0], pa32[1]);
+    bf16x8 xb;
+    if (TWO) {
+      const uint32_t* pb32 = reinterpret_cast<const uint32_t*>(fb + koff[kc]);
+      xb = u8x8_to_bf16(pb32[0], pb32[1]);
+    }
+#pragma unroll
+    for (int t = 2; t >= 0; --t) {                   // smallest weight term first
+      const bf16x8 w = __builtin_bit_cast(bf16x8, w1[kc][t]);
+      acca = MFMA_BF16(w, xa, acca);
+      if (TWO) accb = MFMA_BF16(w, xb, accb);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < (TWO ? 2 : 1); ++h) {
+    const f32x4& acc = h ? accb : acca;
+    const int pos = h ? pb : pa;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(scale * acc[r] + bias[r], 0.f);
+    if (c1_out) *reinterpret_cast<f32x4*>(c1_out + pos * C1_CH + 4 * q) = v;
+    u32x2v pl[3];
+    split4(v, pl);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x2v*>(xp + u * XPL + xrow(pos) * XROW + 8 * q) = pl[u];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
+                                                             const int* __restrict__ frame_idx, float scale,
+                                                             const float* __restrict__ W1, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2,
+                                                             float* __restrict__ c1_out, float* __restrict__ f2_out) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  uint8_t* fr = smem;
+  unsigned char* xp = smem + FWD_X;
+  unsigned char* pp = smem + FWD_P;
+  const unsigned lds_fr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int nt = gw & 1, kh = gw >> 1;         // conv2: this wave's n-tile and K half
+
+  u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], three bf16 terms
+  load_w1_bf16x3(W1, q, i, w1);
+  int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * q);
+  // conv2: B[k = 32kc + 8q + j][col = n = 16nt + i] = W2[(tap = 2kc + (q>>1)) * 16 + 8(q&1) + j][n], kc = 4kh + c
+  bf16x8 w2[4][3];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k0 = 32 * (4 * kh + c) + 8 * q;
+    f32x4 lo4, hi4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo4[j] = W2[(k0 + j) * 32 + 16 * nt + i];
+      hi4[j] = W2[(k0 + 4 + j) * 32 + 16 * nt + i];
+    }
+    u32x2v lo[3], hi[3];
+    split4(lo4, lo);
+    split4(hi4, hi);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+      w2[c][t] = __builtin_bit_cast(bf16x8, w4);
+    }
+  }
+  const float bias2 = b2[16 * nt + i];
+
+  auto dma_frame = [&](int n) {                // uint8 frame n -> FR (lane-linear 1 KiB pieces)
+    const uint8_t* src = frames + (size_t)frame_idx[n] * FRAME_BYTES;
+    for (int kk = gw; kk < FR_DMA; kk += 4) {
+      const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);
+      glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_fr + 1024 * kk));
+    }
+  };
+  const int stride = gridDim.x;
+  dma_frame(blockIdx.x);                       // the launch guarantees gridDim.x <= N
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WG_BARRIER();
+
+  // Two barriers per frame.  [F1] conv1 done: X complete, FR dead -> the DMA of the next frame starts and lands
+  // under conv2.  [F2] conv2 done (every wave has waited for its own DMA pieces first): P complete, FR of the next
+  // frame complete, X dead.  The lower-K waves then add / store the outputs while the upper-K waves already run
+  // conv1 of the next frame; P and X are rewritten only behind the next [F1] / [F2].
+  for (int n = blockIdx.x; n < N; n += stride) {
+    int zero;                                  // opaque 0, new every frame: keeps the address sets out of the registers
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    {
+      float* c1n = c1_out ? c1_out + (size_t)n * (C1_POS * C1_CH) : nullptr;
+      for (int tt = gw; tt < 25; tt += 8) {
+        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt + 4, i + zero, q);
+        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt, i + zero, q);
+      }
+    }
+    WG_BARRIER();     // [F1] c1 planes complete; FR dead
+    if (n + stride < N) dma_frame(n + stride);
+    // conv2: 6 position tiles x this wave's 4 K chunks
+    f32x4 acc[6];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int mt = 0; mt < 6; ++mt) {
+      const int pos = min(16 * mt + i + zero, C2_POS - 1);
+      const int p1 = (2 * (pos / 9)) * 20 + 2 * (pos % 9);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int tap = 2 * (4 * kh + c) + (q >> 1);
+        const unsigned char* src = xp + xrow(p1 + (tap >> 2) * 20 + (tap & 3)) * XROW + 16 * (q & 1);
+        bf16x8 af[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(src + t * XPL);
+        SPLIT_MMA(af, w2[c], a);
+      }
+      if (kh) *reinterpret_cast<f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16) = a;
+      else {
+        // static index for the register array
+        switch (mt) {
+          case 0: acc[0] = a; break;
+          case 1: acc[1] = a; break;
+          case 2: acc[2] = a; break;
+          case 3: acc[3] = a; break;
+          case 4: acc[4] = a; break;
+          default: acc[5] = a; break;
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next frame have landed
+    WG_BARRIER();     // [F2]
+    if (!kh) {
+      float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) {
+        const f32x4 part = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pos = 16 * mt + 4 * q + r;
+          if (pos < C2_POS) dst[pos * C2_CH] = fmaxf((acc[mt][r] + part[r]) + bias2, 0.f);
+        }
+      }
+    }
+  }
 }
 
 template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
@@ -696,8 +705,8 @@ int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float
                        const float* b1, const float* W2, const float* b2, float* c1_out, float* f2_out,
                        void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W1 || !b1 || !W2 || !b2 || !f2_out) return UNREAL_EINVAL;
-  int blocks = min((N + 1) / 2, 256);
-  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames, frame_idx,
+  int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
                      frame_scale, W1, b1, W2, b2, c1_out, f2_out);
   return unreal_launch_status();
 }
