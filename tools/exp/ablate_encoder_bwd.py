@@ -6,7 +6,7 @@ rounds in ONE process on the same random operands (uint8 0..255 frames)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = ["1 1 1", "3 1 1", "1 1 7"]
+VARIANTS = ["1 1 1 p", "1 1 1 n"]
 
 
 def so_of(v):
@@ -18,7 +18,7 @@ if "--build" in sys.argv:
     procs = []
     for v in VARIANTS:
         ks, t, kc = v.split()[:3]
-        extra = []
+        extra = ["-DBWD_PIPE2=" + ("1" if v.endswith("p") else "0")]
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                        "-DUNREAL_ABLATE", "-DBWD_UNROLL_KS=" + ks, "-DBWD_UNROLL_T=" + t, "-DBWD_UNROLL_KC=" + kc] + extra + [
                                        os.path.join(ROOT, "unreal_amd/csrc/encoder.hip"), "-o", so_of(v)]))
@@ -67,3 +67,18 @@ for v in libs:
 best = min(libs, key=lambda v: sorted(res[v])[len(res[v]) // 2])
 for ph in (0, 1, 2, 4):
     print("variant %s phases=%d  %.3f ms" % (best, ph, timed(libs[best], ph)))
+
+if "--stamps" in sys.argv:
+    lib = libs[best]
+    buf = (ctypes.c_ulonglong * 64)()
+    lib.exp_read_stamps(buf, 1)
+    run(lib, 7)
+    lib.exp_read_stamps(buf, 0)
+    names = ["stage planes (tail) + loop", "DMA issue", "wait S0", "phase 1", "wait S1", "phase 2", "wait frame DMA",
+             "wait S2", "prefetch issue + FR reads", "wait S2a", "u8->bf16 + writes", "wait S2b", "phase 3", "wait S3"]
+    iters = (N + 511) // 512
+    for w in range(4):
+        tot = sum(buf[w * 16 + k] for k in range(14))
+        print("wave %d of workgroup 3: %d ticks per frame" % (w, tot // iters))
+        for k in range(14):
+            print("   %-28s %5.1f %%  %7d" % (names[k], 100.0 * buf[w * 16 + k] / max(tot, 1), buf[w * 16 + k] // iters))

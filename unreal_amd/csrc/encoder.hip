@@ -123,6 +123,9 @@ typedef short s16x8v __attribute__((ext_vector_type(8)));
 #ifndef BWD_UNROLL_KC
 #define BWD_UNROLL_KC 1
 #endif
+#ifndef BWD_PIPE2        // explicit software pipelining of phase (2)
+#define BWD_PIPE2 1
+#endif
 constexpr int C1_V = (C1_POS * 4 + 255) / 256;   // f32x4 per thread for one c1 image (7)
 constexpr int D2_V = (C2_POS * 8 + 255) / 256;   // f32x4 per thread for one d2 image (3)
 constexpr int XROW = 32;                         // bytes per conv1 position in a plane (16 bf16)
@@ -351,15 +354,16 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
   }
   const float bias2 = b2[16 * nt + i];
 
-  auto dma_frame = [&](int n) {                // uint8 frame n -> FR (lane-linear 1 KiB pieces)
-    const uint8_t* src = frames + (size_t)frame_idx[n] * FRAME_BYTES;
+  auto dma_frame = [&](int fidx) {             // uint8 frame (pool index fidx) -> FR (lane-linear 1 KiB pieces)
+    const uint8_t* src = frames + (size_t)fidx * FRAME_BYTES;
     for (int kk = gw; kk < FR_DMA; kk += 4) {
       const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);
       glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_fr + 1024 * kk));
     }
   };
   const int stride = gridDim.x;
-  dma_frame(blockIdx.x);                       // the launch guarantees gridDim.x <= N
+  dma_frame(frame_idx[blockIdx.x]);            // the launch guarantees gridDim.x <= N
+  int fidx_next = blockIdx.x + stride < N ? frame_idx[blockIdx.x + stride] : 0;     // fetched one frame ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WG_BARRIER();
 
@@ -378,7 +382,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       }
     }
     WG_BARRIER();     // [F1] c1 planes complete; FR dead
-    if (n + stride < N) dma_frame(n + stride);
+    if (n + stride < N) dma_frame(fidx_next);
+    fidx_next = n + 2 * stride < N ? frame_idx[n + 2 * stride] : 0;
     // conv2: 6 position tiles x this wave's 4 K chunks
     f32x4 acc[6];
 #pragma unroll
@@ -426,6 +431,20 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     }
   }
 }
+
+#ifdef UNREAL_ABLATE     // diagnostic build only (tools/exp/ablate_encoder_bwd.py --stamps): where a wave's cycles go
+__device__ unsigned long long g_stamp_sum[4][16];
+#define STAMP(k)                                                                   \
+  do {                                                                             \
+    if (PHASES == 7 && blockIdx.x == 3 && lane == 0) {                             \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+      g_stamp_sum[gw][k] += t_ - t_prev_;                                          \
+      t_prev_ = t_;                                                                \
+    }                                                                              \
+  } while (0)
+#else
+#define STAMP(k)
+#endif
 
 template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
 __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
@@ -505,11 +524,17 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
     stage_d2_planes(zp, tid, pd2, adb2);
   }
 
+#ifdef UNREAL_ABLATE
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  int fidx = frame_idx[blockIdx.x];       // pool index of the frame, fetched one iteration ahead (a dependent scalar
+                                          // load in front of the DMA would expose an L2 round trip per frame)
   for (int n = blockIdx.x; n < N; n += stride) {
     const int nn = n + stride;
     const bool has_next = nn < N;
+    STAMP(0);       // staging of this frame's planes (tail of the previous iteration) + loop overhead
     {   // uint8 frame n -> FR by LDS-DMA (lane-linear 1 KiB pieces); first needed by phase (3)
-      const uint8_t* src = frames + (size_t)frame_idx[n] * FRAME_BYTES;
+      const uint8_t* src = frames + (size_t)fidx * FRAME_BYTES;
       for (int kk = gw; kk < FR_DMA; kk += 4) {
         const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);      // the overshoot of the last piece re-reads the last chunk
         glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_y + 1024 * kk));
@@ -519,7 +544,9 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
     // the unrolled phases are NOT frame-invariant (hoisted out of the frame loop they occupy ~80 registers and spill)
     int zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    STAMP(1);
     WG_BARRIER();     // [S0] planes of frame n staged
+    STAMP(2);       // wait at S0
     if (PHASES & 1) {
       // (1) conv2 wgrad: dW2[(ky=gw,kx,c)][n] += sum_p c1[2oy+ky][2ox+kx][c] * d2[p][n]; K = 81 positions as 3 x 32
 #pragma unroll BWD_UNROLL_KS
@@ -549,12 +576,48 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
         }
       }
     }
+    STAMP(3);       // phase 1
     WG_BARRIER();     // [S1] all reads of the c1 planes done before d1 overwrites them
+    STAMP(4);       // wait at S1
 
     if (PHASES & 2) {
       // (2) conv2 dgrad, wave gw = output parity: d1^T[c][m] = sum_{dd,n} W2[pa+2da][pb+2db][c][n] * d2[a-da][b-db][n],
       // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16).  Tap (da,db) of position m is halo
       // row m + 11 - (10da + db).
+#if BWD_PIPE2
+      // software-pipelined: the three d2 fragments of the next tap (of the next tile after the last tap) are requested
+      // before the 6 MFMAs of the current one; two fragment sets alternate, sched_barrier pins the order
+      bf16x8 fa[3], fb[3];
+      auto load_tap = [&](int m, int dd, bf16x8 (&dst)[3]) {
+        const int r = m + 11 - 10 * (dd >> 1) - (dd & 1);
+        const unsigned char* zt = zp + r * ZROW + (q ^ ((r & 4) >> 1)) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(zt + pl * ZPL);
+      };
+      int m = min(i + zero, 99);
+      load_tap(m, 0, fa);
+#pragma unroll 1
+      for (int t = 0; t < 7; ++t) {
+        const int mn = min(16 * (t + 1) + i + zero, 99);           // next tile's position (unused after the last)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        load_tap(m, 1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        SPLIT_MMA(wa[0], fa, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(m, 2, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        SPLIT_MMA(wa[1], fb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(m, 3, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        SPLIT_MMA(wa[2], fa, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(mn, 0, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        SPLIT_MMA(wa[3], fb, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ma = m / 10, mb = m - 10 * ma;
+#else
 #pragma unroll BWD_UNROLL_T
       for (int t = 0; t < 7; ++t) {
         const int m = min(16 * t + i + zero, 99);
@@ -569,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
           for (int pl = 0; pl < 3; ++pl) bfr[pl] = *reinterpret_cast<const bf16x8*>(zt + pl * ZPL);
           SPLIT_MMA(wa[dd], bfr, acc);
         }
+#endif
         // acc[r] = d1 of channel 4q + r at position m: ReLU mask from the c1 hi terms it replaces, split, store
         const int pos = (2 * ma + (gw >> 1)) * 20 + 2 * mb + (gw & 1);
         unsigned char* dst = xp + xrow(pos) * XROW + 8 * q;
@@ -586,11 +650,18 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
 #pragma unroll
           for (int e = 0; e < 4; ++e) adb1[e] += g[e];
         }
+#if BWD_PIPE2
+        m = mn;
+#endif
       }
     }
+    STAMP(5);       // phase 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the frame have landed in FR
+    STAMP(6);       // wait for the frame DMA
     WG_BARRIER();     // [S2] d1 planes complete; d2 planes dead; FR complete
+    STAMP(7);       // wait at S2
 
+    const int fidx_next = has_next ? frame_idx[nn] : 0;
     if (has_next) {   // fetch the next frame's c1 and d2 behind phase (3)
       const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)nn * (C1_POS * C1_CH));
 #pragma unroll
@@ -611,7 +682,9 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
       u32x4 raw[FR_V];
 #pragma unroll
       for (int k = 0; k < FR_V; ++k) raw[k] = *reinterpret_cast<const u32x4*>(yp + 16 * min(tid + 256 * k, FR_CHUNKS - 1));
+      STAMP(8);     // prefetch issue + FR reads
       WG_BARRIER();   // [S2a] FR is in registers
+      STAMP(9);     // wait at S2a
 #pragma unroll
       for (int k = 0; k < FR_V; ++k) {
         const int c = tid + 256 * k;
@@ -629,7 +702,9 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
           *reinterpret_cast<u32x4*>(yp + 32 * c + 16) = o[1];
         }
       }
+      STAMP(10);    // conversion + writes
       WG_BARRIER();   // [S2b] bf16 frame image complete
+      STAMP(11);    // wait at S2b
       // (3) conv1 wgrad: A = pixels (one exact bf16 term), B = the three d1 planes; BOTH through transposed reads
       // (K = position).  Wave gw: positions [200*khalf, +200) as 7 chunks of 32 slots (24 of the last are zero
       // padding) x its 6 row tiles.
@@ -657,11 +732,14 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
         }
       }
     }
+    STAMP(12);      // phase 3
     WG_BARRIER();     // [S3] phase (3) finished reading the d1 planes and the frame image
+    STAMP(13);      // wait at S3
     if (has_next) {
       stage_c1_planes(xp, tid, pc1);
       stage_d2_planes(zp, tid, pd2, adb2);
     }
+    fidx = fidx_next;
   }
 
   // flush accumulators (C/D map of the 16x16 MFMAs: col = lane & 15, row = 4 * (lane >> 4) + r)
@@ -723,6 +801,15 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
 }
 
 #ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
+int exp_read_stamps(unsigned long long* host64, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamp_sum), sizeof(unsigned long long) * 64);
+  if (reset) {
+    unsigned long long z[64] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z));
+  }
+  return 0;
+}
 int exp_encoder_bwd_phases(int phases, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
                            const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
                            float* db2, void* stream) {
