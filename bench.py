@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="parallel_size of the reference (options.py:37)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-kernel", default="unreal_encoder_bwd")
+    ap.add_argument("--progress", action="store_true", help="phase markers on stderr (diagnosing a run under a profiler)")
     args = ap.parse_args()
 
     from unreal_amd import parallel
@@ -131,20 +132,35 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
 
+    def mark(msg):
+        if args.progress:
+            torch.cuda.synchronize()
+            print("[bench %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+    mark("device ready")
     flags, net, tr = build_trainer(args, rank, world, device)
     T = flags.n_step_TD
+    mark("trainer built")
 
     t_fill = time.time()
+    k = 0
     while not tr._full:                      # replay warm-up: untimed, global_t frozen
         tr.process(None, 0)
+        k += 1
+        if k % 50 == 0:                      # bound the queue of un-synchronised dispatches: rocprofv3 --pmc segfaults
+            torch.cuda.synchronize()         # in its own thread when ~24 k launches are queued at once (r02_pmc_fault.log)
+        if k in (1, 2, 10, 100, 1000):
+            mark("fill call %d" % k)
     torch.cuda.synchronize()
     t_fill = time.time() - t_fill
+    mark("replay full")
 
     global_t = 0
     for _ in range(args.warmup):
         tr.process(None, global_t, sync_stats=False)
         global_t += args.actors * T * world
     tr.read_stats()
+    mark("warm-up done")
     ops.kernel_timer_start(args.timed_kernel)
     parallel.barrier()
     torch.cuda.synchronize()
