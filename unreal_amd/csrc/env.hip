@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t render_byte(int idx, int ax, int ay) {
 // ONCE in LDS (the per-byte index arithmetic below is ~250 VALU per 16 bytes: rendering every frame from scratch made
 // the step kernel VALU-bound at 1.6 TB/s) and streams it out for each of its actors; the agent block -- 12 rows of 36
 // contiguous bytes (0,1,0)x12, never on a wall cell -- is patched in afterwards as 9 dwords per row.
-constexpr int kActorsPerGroup = 16;
+constexpr int kActorsPerGroup = 8;
 
 __device__ __forceinline__ void build_wall_image(uint4* img) {
   for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) {
