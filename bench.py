@@ -105,8 +105,8 @@ def cpu_baseline(seconds, threads, history):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)       # 100 x 33 ms: a timed region long enough for a 5-s utilisation
+    ap.add_argument("--warmup", type=int, default=5)        # sampler to see (round 1: 10 steps = 0.4 s of GPU work)
     ap.add_argument("--actors", type=int, default=4096, help="actors per GPU (BASELINE.json configs[1])")
     ap.add_argument("--history", type=int, default=2000, help="experience_history_size per actor")
     ap.add_argument("--groups", type=int, default=1, help="sequential updates per process() call (actors are dealt into "
@@ -222,7 +222,7 @@ def main():
                      "whole_path_frac_hbm_u8": value * 114396.0 / (HBM_PEAK_GBS * 1e9 * world)},
     }
     if world == 1 and not args.no_cpu_baseline:
-        hist_cpu = 200
+        hist_cpu = args.history          # the workload's own replay history (its fill is untimed, like the GPU's)
         v, s, el = cpu_baseline(args.cpu_seconds, args.cpu_threads, hist_cpu)
         out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": args.cpu_threads, "kind": "port",
                                "host_cores": os.cpu_count(),

@@ -25,12 +25,18 @@ class OracleRMSProp(object):
         self.ms = None
         self.mom = None
 
+    def create_slots(self, params):
+        """rmsprop_applier.py:38-43: the shared slots exist before any thread runs (graph-build time in the reference);
+        creating them lazily inside step() raced when several threads made their first update at once."""
+        if self.ms is None or self.mom is None:
+            mom = [np.zeros_like(p, dtype=self.dtype) for p in params]
+            ms = [np.ones_like(p, dtype=self.dtype) for p in params]
+            self.mom, self.ms = mom, ms
+
     def step(self, params, grads, lr, clip=True):
         """In-place update of the list of numpy arrays `params`; returns the pre-clip norm."""
         dt = self.dtype
-        if self.ms is None:
-            self.ms = [np.ones_like(p, dtype=dt) for p in params]
-            self.mom = [np.zeros_like(p, dtype=dt) for p in params]
+        self.create_slots(params)
         norm = dt(0)
         if clip:
             grads, norm = clip_by_global_norm(grads, self.clip_norm, dt)

@@ -275,6 +275,7 @@ class OracleTrainer(object):
         npdt = np.float32 if dtype == torch.float32 else np.float64
         self.opt = OracleRMSProp(decay=cfg["rmsp_alpha"], momentum=0.0, epsilon=cfg["rmsp_epsilon"],
                                  clip_norm=cfg["grad_norm_clip"], dtype=npdt)
+        self.opt.create_slots([v.numpy() for v in self.params.values()])
         self.initial_lr = cfg.get("initial_learning_rate",
                                   log_uniform(cfg["initial_alpha_low"], cfg["initial_alpha_high"],
                                               cfg["initial_alpha_log_rate"]))

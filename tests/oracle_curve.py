@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Reference-algorithm learning curve on CPU: the oracle's threaded restatement of main.py:72-162 +
-trainer.py:438-636 (hogwild RMSProp, per-thread replay), logged per finished episode.
-usage: python tools/oracle_curve.py --threads 8 --steps 1000000 --out tests/golden/oracle_curve_maze.json"""
+trainer.py:438-636 (hogwild RMSProp, per-thread replay), logged per finished episode.  Lives under tests/ because it drives the oracle
+(test infrastructure); it is not a test and pytest does not collect it.
+usage: python tests/oracle_curve.py --threads 8 --steps 1000000 --out tests/golden/oracle_curve_maze.json"""
 import argparse, json, os, sys, threading, time
 import numpy as np
 import torch
