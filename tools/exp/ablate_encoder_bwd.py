@@ -6,7 +6,7 @@ rounds in ONE process on the same random operands (uint8 0..255 frames)."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = ["1 1 1 p", "1 1 1 n"]
+VARIANTS = ["1 1 1", "3 1 1", "1 1 7"]
 
 
 def so_of(v):
@@ -18,7 +18,7 @@ if "--build" in sys.argv:
     procs = []
     for v in VARIANTS:
         ks, t, kc = v.split()[:3]
-        extra = ["-DBWD_PIPE2=" + ("1" if v.endswith("p") else "0")]
+        extra = []
         procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                                        "-DUNREAL_ABLATE", "-DBWD_UNROLL_KS=" + ks, "-DBWD_UNROLL_T=" + t, "-DBWD_UNROLL_KC=" + kc] + extra + [
                                        os.path.join(ROOT, "unreal_amd/csrc/encoder.hip"), "-o", so_of(v)]))

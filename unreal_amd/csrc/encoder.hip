@@ -123,9 +123,6 @@ typedef short s16x8v __attribute__((ext_vector_type(8)));
 #ifndef BWD_UNROLL_KC
 #define BWD_UNROLL_KC 1
 #endif
-#ifndef BWD_PIPE2        // explicit software pipelining of phase (2)
-#define BWD_PIPE2 1
-#endif
 constexpr int C1_V = (C1_POS * 4 + 255) / 256;   // f32x4 per thread for one c1 image (7)
 constexpr int D2_V = (C2_POS * 8 + 255) / 256;   // f32x4 per thread for one d2 image (3)
 constexpr int XROW = 32;                         // bytes per conv1 position in a plane (16 bf16)
@@ -584,7 +581,6 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
       // (2) conv2 dgrad, wave gw = output parity: d1^T[c][m] = sum_{dd,n} W2[pa+2da][pb+2db][c][n] * d2[a-da][b-db][n],
       // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16).  Tap (da,db) of position m is halo
       // row m + 11 - (10da + db).
-#if BWD_PIPE2
       // software-pipelined: the three d2 fragments of the next tap (of the next tile after the last tap) are requested
       // before the 6 MFMAs of the current one; two fragment sets alternate, sched_barrier pins the order
       bf16x8 fa[3], fb[3];
@@ -617,22 +613,6 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
         SPLIT_MMA(wa[3], fb, acc);
         __builtin_amdgcn_sched_barrier(0);
         const int ma = m / 10, mb = m - 10 * ma;
-#else
-#pragma unroll BWD_UNROLL_T
-      for (int t = 0; t < 7; ++t) {
-        const int m = min(16 * t + i + zero, 99);
-        const int ma = m / 10, mb = m - 10 * ma;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          const int r = m + 11 - 10 * (dd >> 1) - (dd & 1);
-          const unsigned char* zt = zp + r * ZROW + (q ^ ((r & 4) >> 1)) * 16;
-          bf16x8 bfr[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bfr[pl] = *reinterpret_cast<const bf16x8*>(zt + pl * ZPL);
-          SPLIT_MMA(wa[dd], bfr, acc);
-        }
-#endif
         // acc[r] = d1 of channel 4q + r at position m: ReLU mask from the c1 hi terms it replaces, split, store
         const int pos = (2 * ma + (gw >> 1)) * 20 + 2 * mb + (gw & 1);
         unsigned char* dst = xp + xrow(pos) * XROW + 8 * q;
@@ -650,9 +630,7 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
 #pragma unroll
           for (int e = 0; e < 4; ++e) adb1[e] += g[e];
         }
-#if BWD_PIPE2
         m = mn;
-#endif
       }
     }
     STAMP(5);       // phase 2
