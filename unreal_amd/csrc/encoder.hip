@@ -1,20 +1,19 @@
 // Fused conv encoder for 84x84x3 uint8 frames on gfx950: conv1 8x8 s4 (3->16) + ReLU -> conv2 4x4 s2
-// (16->32) + ReLU, forward and backward, as implicit-GEMM on v_mfma_f32_16x16x4_f32.
+// (16->32) + ReLU, forward and backward, as implicit GEMMs on v_mfma_f32_16x16x32_bf16 with fp32-grade error:
+// every fp32 operand is split ONCE into three bf16 terms (8+8+8 mantissa bits, residuals exact) and a product tile
+// accumulates the six term pairs of weight >= 2^-16 in fp32 (three where one operand is a uint8 pixel, which is
+// exact in one term) -- the scheme of gemm_split.hip.
 //
 // Replaces tf.nn.conv2d + bias + relu of /root/reference/model/model.py:281-289,786-787 and their
 // tf.gradients (train/rmsprop_applier.py:100-105).  Weights are in TF HWIO layout:
 //   W1[(ky*8+kx)*3+cin][16], W2[(ky*4+kx)*16+cin][32]; outputs NHWC (flatten = model.py:331).
 //
-// One frame is processed by a GROUP of 4 waves; a 512-thread workgroup holds two groups that share
-// the LDS copy of W2.  Per group the uint8 frame (21 KB) and the conv1 activation (400 x 16 fp32,
-// row stride 20 floats so that ds_read_b128 im2col reads spread over the banks) live in LDS; the
-// frame is read from HBM exactly once, conv1 output never leaves the CU on the inference path.
-// Global traffic of frame n+1 is issued into registers while frame n is being computed and stored
-// to LDS one phase later, so HBM latency sits behind MFMA work; outputs leave through LDS-staged
-// 16 B/lane stores (full 128 B lines).
-// MFMA operand convention (16x16x4): lane l = (i = l&15, q = l>>4) supplies A[i][k] and B[k][i]
-// for ONE k per instruction; K is walked in a permuted order chosen so that one 32/128-bit LDS
-// read yields the operands of 4 consecutive MFMAs (k = f(chunk(q), s), s = 0..3).
+// Both kernels process ONE frame per 256-thread workgroup at a time and run TWO workgroups per CU (<= 80 KiB of LDS
+// each), so that one workgroup's staging / epilogue VALU overlaps the other's MFMAs; the uint8 frame reaches LDS by
+// LDS-DMA (global_load_lds, 1 KiB per wave instruction) issued a frame ahead; the frame is read from HBM exactly
+// once and conv1's output never leaves the CU on the inference path.
+// MFMA operand convention (16x16x32): lane l = (i = l&15, q = l>>4) supplies A[row i][k = 8q + j] and
+// B[k = 8q + j][col i], j = 0..7; C/D: lane holds rows 4q..4q+3 of column i.
 #include "common.h"
 
 namespace {
@@ -28,8 +27,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // three bf16 terms w = wh + wm + wl (8 + 8 + 8 = 24 mantissa bits, residuals computed exactly in fp32), so
 // three v_mfma_f32_16x16x32_bf16 per 32-deep K chunk give products that are exact in fp32 and are
 // accumulated in fp32 -- fp32-grade numerics at 16/3 of the fp32 MFMA rate.  Lane (i = l&15, q = l>>4)
-// supplies A[pos i][k = 32kc + 8q + j] and B[k = 32kc + 8q + j][cout i], j = 0..7; 8 consecutive k never
-// straddle a patch row (24 bytes per ky), so A is two aligned 32-bit LDS reads of the uint8 frame.
+// supplies the 8 patch elements k = 32kc + 8q + j of position i and of output channel i; 8 consecutive k never
+// straddle a patch row (24 bytes per ky), so the pixel fragment is two aligned 32-bit LDS reads of the uint8 frame.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef u32x4 u32x4v;
 
