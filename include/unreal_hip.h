@@ -37,6 +37,17 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
                      int* r_terminal, int* r_last_action, float* r_last_reward, float* r_pc,
                      float* out_reward, int* out_terminal, float* episode_reward, float* score_out,
                      int* score_valid, int reset_on_terminal, int track_score, void* stream);
+/* the same step with the rollout loop's bookkeeping (train/trainer.py:236-296) in the same launch: `active` is read
+ * AND updated (an actor leaves the rollout at its terminal, the reference's `break`), active_log_t / n_steps /
+ * terminal_end as unreal_rollout_advance writes them, next_idx = ring index of every actor's next observation
+ * (unreal_ring_cur_idx) and next_lar = the [one-hot last action | last reward] columns of the next step's LSTM-input
+ * rows (unreal_lar_fill): three ~5 us launches per rollout step less.  reset_on_terminal = track_score = 1. */
+int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* last_action, float* last_reward, int* count,
+                             uint8_t* frames, float* r_reward, int* r_action, int* r_terminal, int* r_last_action,
+                             float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
+                             float* episode_reward, float* score_out, int* score_valid, int* active,
+                             int* active_log_t, int* n_steps, int* terminal_end, int* next_idx /*nullable*/,
+                             float* next_lar /*nullable*/, int lar_ld, int lar_col0, int A, void* stream);
 int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
                       const int* count, uint8_t* frames, void* stream);
 /* host-fed environments (environment/lab_environment.py:78-119 contract): `staged` holds one uint8

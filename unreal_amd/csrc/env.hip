@@ -116,6 +116,14 @@ struct StepArgs {
   int* score_valid;
   int reset_on_terminal;
   int track_score;
+  // rollout bookkeeping fused into the step (unreal_maze_rollout_step; all null / 0 for the plain step):
+  int* active_rw;        // in: actor still inside its rollout; out: cleared at its terminal (trainer.py:279-296 `break`)
+  int* active_log_t;     // active flag of this step (row mask of the losses)
+  int* n_steps;          // += 1 per step taken
+  int* terminal_end;     // set at the terminal
+  int* next_idx;         // nullable: ring index of the NEXT observation (b * H1 + slot), also for idle actors
+  float* next_lar;       // nullable: [B][lar_ld] rows of the next step's LSTM input: one-hot last action | last reward
+  int lar_ld, lar_col0, A;
 };
 
 __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
@@ -126,7 +134,21 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   for (int k = 0; k < kActorsPerGroup; ++k) {
     const int b = blockIdx.x * kActorsPerGroup + k;
     if (b >= p.B) break;
-    if (p.active && !p.active[b]) continue;
+    const int act_flag = p.active_rw ? p.active_rw[b] : (p.active ? p.active[b] : 1);
+    if (p.active_rw && threadIdx.x == 0) p.active_log_t[b] = act_flag;
+    if (!act_flag) {
+      // idle for the rest of the rollout: its observation and last action / reward stay what they are
+      if (threadIdx.x == 0) {
+        if (p.next_idx) p.next_idx[b] = b * H1 + p.count[b] % H1;
+        if (p.next_lar) {
+          float* row = p.next_lar + (size_t)b * p.lar_ld + p.lar_col0;
+          const int la0 = p.last_action[b];
+          for (int e = 0; e < p.A; ++e) row[e] = (e == la0) ? 1.f : 0.f;
+          row[p.A] = p.last_reward[b];
+        }
+      }
+      continue;
+    }
     const int x = p.pos[2 * b], y = p.pos[2 * b + 1];
     const int a = p.actions[b];
     const int cnt = p.count[b];
@@ -189,6 +211,20 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
           ep = 0.f;
         }
         p.episode_reward[b] = ep;
+      }
+      if (p.active_rw) {
+        p.n_steps[b] += 1;
+        if (terminal) {
+          p.active_rw[b] = 0;
+          p.terminal_end[b] = 1;
+        }
+      }
+      if (p.next_idx) p.next_idx[b] = b * H1 + nslot;
+      if (p.next_lar) {
+        float* row = p.next_lar + (size_t)b * p.lar_ld + p.lar_col0;
+        const int la1 = reset ? 0 : a;
+        for (int e = 0; e < p.A; ++e) row[e] = (e == la1) ? 1.f : 0.f;
+        row[p.A] = reset ? 0.f : reward;
       }
     }
   }
@@ -415,7 +451,26 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
   if (track_score && (!episode_reward || !score_out || !score_valid)) return UNREAL_EINVAL;
   StepArgs p{B, H1, actions, active, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
-             score_out, score_valid, reset_on_terminal, track_score};
+             score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
+             nullptr, 0, 0, 0};
+  hipLaunchKernelGGL(maze_step_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  return unreal_launch_status();
+}
+
+int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* last_action, float* last_reward, int* count,
+                             uint8_t* frames, float* r_reward, int* r_action, int* r_terminal, int* r_last_action,
+                             float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
+                             float* episode_reward, float* score_out, int* score_valid, int* active,
+                             int* active_log_t, int* n_steps, int* terminal_end, int* next_idx, float* next_lar,
+                             int lar_ld, int lar_col0, int A, void* stream) {
+  if (B <= 0 || H1 < 2 || !actions || !pos || !count || !frames || !last_action || !last_reward) return UNREAL_EINVAL;
+  if (!episode_reward || !score_out || !score_valid || !active || !active_log_t || !n_steps || !terminal_end)
+    return UNREAL_EINVAL;
+  if (next_lar && (A <= 0 || lar_col0 < 0 || lar_ld < lar_col0 + A + 1)) return UNREAL_EINVAL;
+  StepArgs p{B, H1, actions, nullptr, pos, last_action, last_reward, count, frames, r_reward, r_action,
+             r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
+             score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
+             lar_col0, A};
   hipLaunchKernelGGL(maze_step_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }

@@ -37,6 +37,11 @@ class BatchedMazeEnvironment(object):
                 track_score=False):
         ops.maze_step(self.ring, actions, active, out_reward, out_terminal, reset_on_terminal, track_score)
 
+    def rollout_step(self, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end, **nxt):
+        """process() + the rollout loop's bookkeeping (+ the next step's frame indices / LSTM-input columns) fused."""
+        ops.maze_rollout_step(self.ring, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
+                              **nxt)
+
     def stop(self):
         pass
 

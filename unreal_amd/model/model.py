@@ -267,7 +267,7 @@ class UnrealModel(object):
 
     # -- batched building blocks -----------------------------------------------------------------------
     def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
-                    objective_slot_offset=0, actor_ring=None):
+                    objective_slot_offset=0, actor_ring=None, lar_prefilled=False):
         """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
         rows [row0, row0+nrows) of a path workspace.  `objective_slot_offset` = -1 reproduces trainer.py:300, where the
         bootstrap value is fed the objective of the previous frame's state."""
@@ -284,7 +284,9 @@ class UnrealModel(object):
         if not self._use_lstm:
             return
         A = self._action_size
-        if lar_from_ring:
+        if lar_prefilled:
+            pass                   # the environment step kernel has written the [last action | last reward] columns
+        elif lar_from_ring:
             ops.lar_fill(nrows, A, ring.r_last_action, ring.r_last_reward, idx, xcat, self.xld)
         else:
             ar = ring if actor_ring is None else actor_ring     # per-actor state of a sub-range of the ring's actors

@@ -135,6 +135,22 @@ def maze_step(ring, actions, active=None, out_reward=None, out_terminal=None, re
           ptr(ring.score_valid), int(reset_on_terminal), int(track_score))
 
 
+def maze_rollout_step(ring, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
+                      next_idx=None, next_lar=None, lar_ld=0, lar_col0=0, A=0):
+    """maze_step + rollout_advance (+ cur_idx and lar_fill for the NEXT step's rows) in one launch."""
+    B = ring.B
+    _chk(actions, "i32", B, "actions"); _chk(out_reward, "f32", B, "out_reward"); _chk(out_terminal, "i32", B, "out_terminal")
+    for t in (active, active_log_t, n_steps, terminal_end):
+        _chk(t, "i32", B)
+    _chk(next_idx, "i32", B, "next_idx", optional=True)
+    _chk(next_lar, "f32", (B - 1) * lar_ld + lar_col0 + A + 1 if next_lar is not None else None, "next_lar", optional=True)
+    _call("unreal_maze_rollout_step", B, ring.H1, ptr(actions), ptr(ring.pos), ptr(ring.last_action), ptr(ring.last_reward),
+          ptr(ring.count), ptr(ring.frames), ptr(ring.r_reward), ptr(ring.r_action), ptr(ring.r_terminal),
+          ptr(ring.r_last_action), ptr(ring.r_last_reward), ptr(ring.r_pc), ptr(out_reward), ptr(out_terminal),
+          ptr(ring.episode_reward), ptr(ring.score_out), ptr(ring.score_valid), ptr(active), ptr(active_log_t),
+          ptr(n_steps), ptr(terminal_end), ptr(next_idx), ptr(next_lar), int(lar_ld), int(lar_col0), int(A))
+
+
 def pixel_change_u8(frames, idx_new, idx_old, denom, out):
     N = idx_new.numel()
     _chk(frames, "u8"); _chk(idx_new, "i32", N); _chk(idx_old, "i32", N); _chk(out, "f32", N * PC_CELLS)

@@ -225,11 +225,14 @@ class Trainer(object):
         raise NotImplementedError("actions are drawn on the device; see ops.softmax_sample")
 
     # ---------------------------------------------------------------------------------------------------
-    def _policy_step(self, ws, t, u, actions_out, pi_out, v_out):
-        """Forward the current observations of all actors as time row-block t of `ws` and draw actions."""
+    def _policy_step(self, ws, t, u, actions_out, pi_out, v_out, prefilled=False):
+        """Forward the current observations of all actors as time row-block t of `ws` and draw actions.  `prefilled`:
+        the previous environment step has already written this block's frame indices and last_action_reward columns."""
         B, A, net = self.Bg, self.action_size, self.local_network
-        self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
-        net.encode_rows(self.ring, ws, t * B, B, lar_from_ring=False, save_c1=ws.c1 is not None)
+        if not prefilled:
+            self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
+        net.encode_rows(self.ring, ws, t * B, B, lar_from_ring=False, save_c1=ws.c1 is not None,
+                        lar_prefilled=prefilled and self.use_lstm)
         if self.use_lstm:
             net.lstm_step(ws, t, B)
         feat, ld = net.features(ws, t * B)
@@ -323,9 +326,20 @@ class Trainer(object):
         self.draws.uniform(self.u_act)
         if self.overlap_host:
             self._rollout_steps_overlapped()
+        fused = self.env_type == "maze"      # the maze step kernel also does the loop bookkeeping and prepares step t+1
         for t in range(0 if not self.overlap_host else T, T):
             s = slice(t * B, (t + 1) * B)
-            self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s])
+            self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s],
+                              prefilled=fused and t > 0)
+            if fused:
+                nxt = {}
+                if t + 1 < T:
+                    nxt = dict(next_idx=ws.frame_idx[(t + 1) * B:(t + 2) * B])
+                    if self.use_lstm:
+                        nxt.update(next_lar=ws.xcat[(t + 1) * B * ws.xld:], lar_ld=ws.xld, lar_col0=256, A=A)
+                self.environment.rollout_step(self.actions[s], self.rewards[s], self.terminals[s], self.active,
+                                              self.active_log[s], self.n_steps, self.terminal_end, **nxt)
+                continue
             self.environment.process(self.actions[s], self.active, self.rewards[s], self.terminals[s],
                                      reset_on_terminal=True, track_score=True)
             ops.rollout_advance(B, self.terminals[s], self.active, self.active_log[s], self.n_steps,
