@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     {
       float* c1n = c1_out ? c1_out + (size_t)n * (C1_POS * C1_CH) : nullptr;
-      for (int tt = gw; tt < 25; tt += 8) {
+      // 25 tiles over 4 waves = 7 + 6 + 6 + 6: the extra tile goes to an upper-K wave (gw = 2), which has no output
+      // epilogue to do after conv2
+      for (int tt = (gw + 2) & 3; tt < 25; tt += 8) {
         if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt + 4, i + zero, q);
         else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt, i + zero, q);
       }
