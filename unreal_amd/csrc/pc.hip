@@ -170,20 +170,23 @@ __device__ __forceinline__ void deconv_packed(const unsigned char* hpp, const un
   }
 }
 
-__global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FWD_GRP_BYTES + 3 * WDP_PLANE];
-  const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
+// One frame per 256-thread workgroup at a time, TWO independent workgroups per CU (76.5 KB of LDS each, weight planes
+// included): round 1 ran two frame groups in lock-step inside one 512-thread workgroup (matrix pipe busy 0.18, waves
+// parked 56 %); independent workgroups let one's dueling / loss VALU phase overlap the other's MFMAs.
+__global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_GRP_BYTES + 3 * WDP_PLANE];
+  const int gtid = threadIdx.x;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  unsigned char* hpp = smem + grp * FWD_GRP_BYTES;
+  unsigned char* hpp = smem;
   float* dec = reinterpret_cast<float*>(hpp + 3 * HPP_PLANE);
   float* dout = dec + PC_CELLS * DEC_LD_F;      // staged d_dec of the frame: [400][CO] dense
-  unsigned char* wdp = smem + 2 * FWD_GRP_BYTES;
+  unsigned char* wdp = smem + FWD_GRP_BYTES;
   const int A = p.A, CO = 1 + p.A;
 
   // weights -> bf16x3 planes [plane][dd][n = par*CO + co (32, zero padded)][ci(32)]: tap dd of parity par is
   // W[pa + 2da][pb + 2db][co][ci]
-  for (int e = threadIdx.x; e < 4 * 32 * 8; e += 512) {      // one f32x4 of ci per item
+  for (int e = threadIdx.x; e < 4 * 32 * 8; e += 256) {      // one f32x4 of ci per item
     const int c4 = e & 7, n = (e >> 3) & 31, dd = e >> 8;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (n < 4 * CO) {
@@ -211,18 +214,18 @@ __global__ __launch_bounds__(512) void pc_deconv_fwd_kernel(PcFwdArgs p) {
   const bool two_nt = 4 * CO > 16;
   float loss_acc = 0.f;
 
-  const int stride = gridDim.x * 2;
+  const int stride = gridDim.x;
   f32x4 pre[HP_V];
   {
-    const int n0 = blockIdx.x * 2 + grp;
+    const int n0 = blockIdx.x;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre);
       hp_store_planes(hpp, gtid, pre);
     }
   }
   int prev = -1;
-  for (int base = blockIdx.x * 2; base < p.N; base += stride) {
-    const int n = base + grp;
+  for (int base = blockIdx.x; base < p.N; base += stride) {
+    const int n = base;
     const bool valid = n < p.N;
     const int nn = n + stride;
     const bool has_next = nn < p.N;
@@ -331,19 +334,21 @@ __device__ __forceinline__ void split1p(float x, unsigned short (&t)[3]) {
   }
 }
 
-__global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BWD_GRP_BYTES + 3 * WBP_PLANE];
-  const int grp = threadIdx.x >> 8, gtid = threadIdx.x & 255;
+// one frame per 256-thread workgroup at a time, two independent workgroups per CU (80.6 KB of LDS each), like the forward
+__global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_GRP_BYTES + 3 * WBP_PLANE];
+  static_assert(2 * (BWD_GRP_BYTES + 3 * WBP_PLANE) <= 160 * 1024, "two workgroups must fit one CU's LDS");
+  const int gtid = threadIdx.x;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  unsigned char* hpp = smem + grp * BWD_GRP_BYTES;
+  unsigned char* hpp = smem;
   unsigned char* ddp = hpp + 3 * HPP_PLANE;
   float* dhs = reinterpret_cast<float*>(ddp + 3 * DDP_PLANE);      // staged d_hp of the frame: [81][32] dense
-  unsigned char* wbp = smem + 2 * BWD_GRP_BYTES;
+  unsigned char* wbp = smem + BWD_GRP_BYTES;
   const int A = p.A, CO = 1 + p.A;
 
   // weights -> bf16x3 planes [plane][ky][ci(32)][k = kx*8 + co (32, co >= CO zero)]
-  for (int e = threadIdx.x; e < 4 * 32 * 32; e += 512) {
+  for (int e = threadIdx.x; e < 4 * 32 * 32; e += 256) {
     const int k = e & 31, ci = (e >> 5) & 31, ky = e >> 10;
     const int kx = k >> 3, co = k & 7;
     float v = 0.f;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
   const int n_dd4 = PC_CELLS * CO / 4;           // f32x4 in one frame's d_dec
   const int qq = i >> 2, pp = i & 3;             // transposed reads: lane (4qq + pp) of a 16-lane group addresses block row qq
 
-  const int stride = gridDim.x * 2;
+  const int stride = gridDim.x;
   f32x4 pre_hp[HP_V], pre_dd[DD_V];
 
   // scatter one frame's d_dec (registers, [400][CO] dense) into the planes + bias-gradient sums
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
 
   __syncthreads();   // zero fills visible before the first scatter
   {
-    const int n0 = blockIdx.x * 2 + grp;
+    const int n0 = blockIdx.x;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
       hp_store_planes(hpp, gtid, pre_hp);
@@ -417,8 +422,8 @@ __global__ __launch_bounds__(512) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       stage_dd(pre_dd);
     }
   }
-  for (int base = blockIdx.x * 2; base < p.N; base += stride) {
-    const int n = base + grp;
+  for (int base = blockIdx.x; base < p.N; base += stride) {
+    const int n = base;
     const bool valid = n < p.N;
     const int nn = n + stride;
     const bool has_next = nn < p.N;
@@ -542,8 +547,8 @@ int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const f
   if (d_dec && (!action || !target || !mask || !loss)) return UNREAL_EINVAL;
   if ((((uintptr_t)hp) | ((uintptr_t)d_dec)) & 15) return UNREAL_EINVAL;
   PcFwdArgs p{N, A, hp, Wv, bv, Wa, ba, qmax, action, target, mask, lambda, grad_scale, d_dec, d_dec ? loss : nullptr};
-  int blocks = min((N + 1) / 2, 256);
-  hipLaunchKernelGGL(pc_deconv_fwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, p);
+  int blocks = min(N, 512);
+  hipLaunchKernelGGL(pc_deconv_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
@@ -553,8 +558,8 @@ int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, cons
     return UNREAL_EINVAL;
   if ((((uintptr_t)hp) | ((uintptr_t)d_dec) | ((uintptr_t)d_hp)) & 15) return UNREAL_EINVAL;
   PcBwdArgs p{N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba};
-  int blocks = min((N + 1) / 2, 256);
-  hipLaunchKernelGGL(pc_deconv_bwd_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, p);
+  int blocks = min(N, 512);
+  hipLaunchKernelGGL(pc_deconv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
