@@ -154,13 +154,17 @@ int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int tr
                         int ld_dst, long plane_stride, void* stream);
 /* row_perm = 1 (1024 output rows only): LSTM gate interleave, output row of column n = g*256 + u of the kernel is
  * (u/16)*64 + g*16 + u%16, the layout unreal_lstm_step_fwd multiplies by. */
-/* One BasicLSTMCell step (model/model.py:110,346-351; gates i,j,f,o, forget_bias 1): the recurrent half
- * h_prev[rows,256] * Wh is multiplied on the split-operand path and the gate math runs in the GEMM epilogue.
- * gates [rows][1024]: in = input-half pre-activations (x * Wx), out = activated gates (saved for the backward);
- * Wh3 = gate-interleaved bf16x3 shadow of the kernel's recurrent rows (transpose = 1, row_perm = 1). */
-int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint16_t* Wh3, int ldw, long plane_stride,
-                         float* gates, const float* bias, const float* c_prev, float* c_out, float* h_out, int ld_h,
-                         void* stream);
+/* One BasicLSTMCell step (model/model.py:110,346-351; gates i,j,f,o, forget_bias 1) on the split-operand path with the
+ * gate math in the GEMM epilogue.  gates [rows][1024]: out = activated gates (saved for the backward).
+ *   x == NULL: gates holds the input-half pre-activations (x * Wx, hoisted over all T steps of a training sequence)
+ *              on entry; W3 = gate-interleaved bf16x3 shadow of the kernel's recurrent rows [1024][256]
+ *              (unreal_split_bf16x3 transpose = 1, row_perm = 1) and only h_prev[rows,256] * Wh is multiplied here;
+ *   x != NULL: the cell's own product [x | h_prev] @ kernel in ONE launch (a rollout step, where the input half cannot
+ *              be hoisted): x[rows][Kx] (row stride ldx), W3 = gate-interleaved shadow of the WHOLE kernel,
+ *              [1024][pad32(Kx) + 256]: columns [0, Kx) the input rows, zeros up to pad32(Kx), then the recurrent rows. */
+int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* h_prev, int ld_hprev, const uint16_t* W3,
+                         int ldw, long plane_stride, float* gates, const float* bias, const float* c_prev, float* c_out,
+                         float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
                           float* c_out, float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,

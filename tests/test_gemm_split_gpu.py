@@ -13,7 +13,8 @@ def dev(a):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 256, 2592), (200, 1024, 261), (4096, 256, 512), (7, 5, 3), (130, 2592, 256),
-                                   (33, 261, 1024), (640, 384, 96)])
+                                   (33, 261, 1024), (640, 384, 96),
+                                   (4096, 256, 2592), (1500, 1024, 200)])    # 4 / 2 wave groups share a tile's K range
 def test_split_gemm_matches_fp64(M, N, K):
     from unreal_amd import ops
     rs = np.random.RandomState(M + N + K)
@@ -62,6 +63,42 @@ def test_split_gemm_matches_fp64(M, N, K):
         ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, splitk=2)                    # split-K needs ATOMIC
 
 
+@pytest.mark.parametrize("rows,A,obj", [(4096, 4, 0), (70, 3, 7), (3, 6, 0)])
+def test_whole_kernel_lstm_step_matches_hoisted_chain_and_fp64(rows, A, obj):
+    """unreal_lstm_step_fwd(x=...) -- [x | h] @ kernel in one launch, as a rollout step runs it -- against (a) the
+    chain it replaces (input-half GEMM, then the recurrent step) at the fp32 tolerance (the two differ only in the
+    order the two halves are summed) and (b) a float64 BasicLSTMCell step."""
+    from unreal_amd import ops
+    from unreal_amd.model.model import xcat_ld
+    rs = np.random.RandomState(rows + A)
+    K_x, xld = 256 + A + 1 + obj, xcat_ld(A, obj)
+    W = rs.uniform(-0.07, 0.07, size=(K_x + 256, 1024)); bias = rs.uniform(-0.1, 0.1, size=1024)
+    x = rs.uniform(-1, 1, size=(rows, xld)); x[:, K_x:] = 1e30          # padding columns must never be read as data
+    h_prev = rs.uniform(-1, 1, size=(rows, 256)); c_prev = rs.uniform(-2, 2, size=(rows, 256))
+    Wd = dev(W).view(-1)
+    sh_x = ops.SplitWeights(Wd, K_x, 1024, 1024, True)
+    sh_h = ops.SplitWeights(Wd, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1)
+    sh_xh = ops.LstmKernelShadow(Wd, K_x)
+    xd, hd, cd, bd = dev(x).view(-1), dev(h_prev).view(-1), dev(c_prev).view(-1), dev(bias)
+    g0 = torch.zeros(rows * 1024, device=DEV); c0 = torch.zeros(rows * 256, device=DEV); h0 = torch.zeros(rows * 256, device=DEV)
+    ops.gemm_split_nt(rows, 1024, K_x, xd, xld, sh_x, g0, 1024)
+    ops.lstm_step_fwd(rows, hd, sh_h, g0, bd, cd, c0, h0)
+    g1 = torch.full((rows * 1024,), 5.0, device=DEV); c1 = torch.zeros(rows * 256, device=DEV); h1 = torch.zeros(rows * 256, device=DEV)
+    ops.lstm_step_fwd(rows, hd, sh_xh, g1, bd, cd, c1, h1, x=xd, ldx=xld, Kx=K_x)
+    for a, b in ((g0, g1), (c0, c1), (h0, h1)):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-6, rtol=2e-6)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    pre = f32(x[:, :K_x]) @ f32(W[:K_x]) + f32(h_prev) @ f32(W[K_x:]) + bias
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    i, j, f, o = sig(pre[:, :256]), np.tanh(pre[:, 256:512]), sig(pre[:, 512:768] + 1.0), sig(pre[:, 768:])
+    c = c_prev * f + i * j
+    np.testing.assert_allclose(c1.cpu().numpy().reshape(rows, 256), c, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(h1.cpu().numpy().reshape(rows, 256), np.tanh(c) * o, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(g1.cpu().numpy().reshape(rows, 1024), np.concatenate([i, j, f, o], 1), atol=2e-5, rtol=2e-5)
+    with pytest.raises(ValueError):                      # the recurrent-only shadow is not the whole kernel
+        ops.lstm_step_fwd(rows, hd, sh_h, g1, bd, cd, c1, h1, x=xd, ldx=xld, Kx=K_x)
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(2592, 256, 4000, 9), (256, 1024, 333, 1), (261, 1024, 70, 2), (256, 2592, 2100, 25),
                                       (5, 7, 3, 1), (130, 129, 4096, 16)])
 def test_split_tn_wgrad_matches_fp64(M, N, K, sk):
@@ -101,8 +138,9 @@ def test_split_tn_wgrad_matches_fp64(M, N, K, sk):
 
 @pytest.mark.parametrize("rows", [4096, 70, 3])
 def test_fused_lstm_step_matches_unfused_and_fp64(rows):
-    """unreal_lstm_step_fwd == split GEMM (accumulate) + unreal_lstm_gates_fwd bit for bit (same association of the
-    sums), and both match a float64 BasicLSTMCell step (gates i,j,f,o, forget_bias 1)."""
+    """unreal_lstm_step_fwd == split GEMM (accumulate) + unreal_lstm_gates_fwd, and both match a float64 BasicLSTMCell
+    step (gates i,j,f,o, forget_bias 1).  Bit for bit at the production row count (same association of the sums); with
+    few rows the stand-alone GEMM deals a tile's K range to several wave groups, so the sums associate differently."""
     from unreal_amd import ops
     rs = np.random.RandomState(rows)
     Wh = rs.uniform(-0.07, 0.07, size=(256, 1024)); bias = rs.uniform(-0.1, 0.1, size=1024)
@@ -118,9 +156,12 @@ def test_fused_lstm_step_matches_unfused_and_fp64(rows):
     # fused
     g1 = dev(pre_x).view(-1); c1 = torch.zeros(rows * 256, device=DEV); h1 = torch.full((rows * 264,), 3.0, device=DEV)
     ops.lstm_step_fwd(rows, dev(h_prev).view(-1), sh_il, g1, dev(bias), dev(c_prev).view(-1), c1, h1, ld_h=264)
-    assert torch.equal(g0, g1) and torch.equal(c0, c1)
     h1m = h1.view(rows, 264)
-    assert torch.equal(h0.view(rows, 256), h1m[:, :256]) and float(h1m[:, 256:].min()) == 3.0
+    if rows >= 4096:
+        assert torch.equal(g0, g1) and torch.equal(c0, c1) and torch.equal(h0.view(rows, 256), h1m[:, :256])
+    for a, b in ((g0, g1), (c0, c1), (h0.view(rows, 256), h1m[:, :256])):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=2e-6, rtol=2e-6)
+    assert float(h1m[:, 256:].min()) == 3.0
     # float64
     pre = pre_x + h_prev.astype(np.float32).astype(np.float64) @ Wh.astype(np.float32).astype(np.float64) + bias
     sig = lambda x: 1.0 / (1.0 + np.exp(-x))

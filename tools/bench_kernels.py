@@ -89,6 +89,25 @@ def main():
                            flop=2.0 * M * N * K)
             del A_, Bt_, C_
 
+    if not FILT or FILT in "split gemm lstm":
+        K_x, xld = 261, 264
+        Wk = rnd((K_x + 256) * 1024) * .05
+        sh_x = ops.SplitWeights(Wk, K_x, 1024, 1024, True)
+        sh_h = ops.SplitWeights(Wk, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1)
+        sh_xh = ops.LstmKernelShadow(Wk, K_x)
+        x_, h_, c_, b_ = rnd(B * xld), rnd(B * 256), rnd(B * 256), rnd(1024)
+        g_, c2, h2 = torch.zeros(B * 1024, device=DEV), torch.zeros(B * 256, device=DEV), torch.zeros(B * 256, device=DEV)
+
+        def chain():
+            ops.gemm_split_nt(B, 1024, K_x, x_, xld, sh_x, g_, 1024)
+            ops.lstm_step_fwd(B, h_, sh_h, g_, b_, c_, c2, h2)
+        report("lstm step, chain (x GEMM + h step) rows=%d" % B, timeit(chain), flop=2.0 * B * 1024 * (K_x + 256))
+        report("lstm step, h half only rows=%d" % B, timeit(lambda: ops.lstm_step_fwd(B, h_, sh_h, g_, b_, c_, c2, h2)),
+               flop=2.0 * B * 1024 * 256)
+        report("lstm step, whole kernel rows=%d" % B,
+               timeit(lambda: ops.lstm_step_fwd(B, h_, sh_xh, g_, b_, c_, c2, h2, x=x_, ldx=xld, Kx=K_x)),
+               flop=2.0 * B * 1024 * (K_x + 256))
+
     if not FILT or FILT in "split gemm tn":
         for name, M, N, K in (("dW_fc1", 2592, 256, R), ("dW_lstm_x", 256, 1024, R), ("dW_lstm_h", 256, 1024, R - B),
                               ("dW_pc_fc1", 256, 2592, R)):

@@ -51,6 +51,8 @@ struct SplitArgs {
   int splitk, ktiles_per_split;        // > 1 only with FLAG_ATOMIC: K slabs added into C with fp32 atomics
   // fused LSTM step (EPI == 1): C is the gate buffer [M][1024] (in: input-half pre-activations, out: activated gates)
   const float* c_prev; float* c_out; float* h_out; int ld_h;
+  // DUAL: A operand = [A (K1 valid columns, k < K1pad) | A2 (K - K1pad columns)]
+  const float* A2; int lda2, K1, K1pad;
 };
 
 // One 16-byte piece of the A tile per call (piece p of ROWS*BK/1024).  Branch-free on purpose: rows past the end
@@ -59,8 +61,9 @@ struct SplitArgs {
 // uniform branches here break the K loop into several basic blocks and the MFMA / VALU / load interleave is lost
 // (with divergent ones the compiler also serialises the loads with s_waitcnt vmcnt(0)).
 template <int ROWS, bool VEC>
-__device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int ld, int rows_total, int K, int r0, int k0, int p) {
-  const int id = threadIdx.x + 256 * p;
+__device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int ld, int rows_total, int K, int r0, int k0, int p,
+                                              int tid) {
+  const int id = tid + 256 * p;
   const int r = (SPLIT_ABLATE & 8) ? (id / (BK / 4)) & 7 : min(r0 + id / (BK / 4), rows_total - 1);
   const int k = k0 + (id % (BK / 4)) * 4;
   const float* row = P + (size_t)r * ld;
@@ -104,8 +107,8 @@ __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float
 
 // split 4 consecutive-k fp32 values into three bf16 planes and store 8 bytes per plane; klim = K - k0 of that tile
 template <int ROWS>
-__device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p) {
-  const int id = threadIdx.x + 256 * p;
+__device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p, int tid) {
+  const int id = tid + 256 * p;
   const int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? v[e] : 0.f;
@@ -119,16 +122,16 @@ __device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int kli
 // weight tile piece: 3 planes x ROWS rows x 64 B, 16 B per lane (planes are zero-padded in k, rows clamped)
 template <int ROWS>
 __device__ __forceinline__ u32x4 w_piece_load(const unsigned short* __restrict__ W, int ldw, long plane, int rows_total,
-                                              int r0, int k0, int p) {
-  const int id = threadIdx.x + 256 * p;
+                                              int r0, int k0, int p, int tid) {
+  const int id = tid + 256 * p;
   const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
   const int row = min(r0 + r, rows_total - 1);
   return *reinterpret_cast<const u32x4*>(W + t * plane + (size_t)row * ldw + k0 + c * 8);
 }
 
 template <int ROWS>
-__device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p) {
-  const int id = threadIdx.x + 256 * p;
+__device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p, int tid) {
+  const int id = tid + 256 * p;
   const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
   *reinterpret_cast<u32x4*>(S + (t * ROWS + r) * ROW_B + c * 16) = v;
 }
@@ -173,14 +176,44 @@ __device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x
 
 // DEEP: activation tiles travel two K tiles ahead instead of one.  Measured on one device, same process: +20 % on the
 // 64x64 kernel's long-K shapes (4096 x 256 x 2592: 76 -> 62 us), -3 % on the 128x128 kernel (16 more live registers).
-template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0>
-__global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
+//
+// KW (64x64 tiles of the 4096-row rollout / BPTT steps): KW groups of 4 waves share ONE output tile and deal its K tiles
+// round-robin (group g takes tiles g, g + KW, ...), each with its own LDS image; their partial tiles are summed in a
+// fixed order in the epilogue.  A 4096 x 256 product has only 256 tiles of 64 x 64 -- one 4-wave workgroup per CU, one
+// wave per SIMD, nothing to hide an LDS read or a barrier behind; with KW = 4 the same tile keeps 4 waves per SIMD busy
+// without fetching any operand byte twice (smaller tiles would) and without a zero-fill + atomics pass (split-K over
+// workgroups would).
+//
+// DUAL (the LSTM step of a rollout): the A operand is the row-wise concatenation [A | A2] -- k < K1pad comes from A
+// (K1 valid columns, zero beyond), the rest from A2 -- multiplied by ONE weight shadow laid out the same way, so the
+// input half and the recurrent half of the gates are one product (BasicLSTMCell's own [x, h] @ kernel, model.py:110).
+template <bool DUAL>
+struct ASrc { const float* P; int ld, K, k0; };
+
+template <bool DUAL>
+__device__ __forceinline__ ASrc<DUAL> a_src(const SplitArgs& p, int kg) {
+  ASrc<DUAL> s;
+  if (DUAL) {
+    const bool second = kg >= p.K1pad;
+    s.P = second ? p.A2 : p.A; s.ld = second ? p.lda2 : p.lda;
+    s.K = second ? p.K - p.K1pad : p.K1; s.k0 = second ? kg - p.K1pad : kg;
+  } else {
+    s.P = p.A; s.ld = p.lda; s.K = p.K; s.k0 = kg;
+  }
+  return s;
+}
+
+template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false>
+__global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int PA = BM * BK / 1024, PW = 3 * BN / 64;
   constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
   constexpr int C_BYTES = BM * (BN + 4) * 4;
   constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[KW * SMEM];
+  const int tid = KW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);
+  const int grp = KW == 1 ? 0 : (int)(threadIdx.x >> 8);
+  unsigned char* smem = smem_all + grp * SMEM;
   unsigned char* As = smem;
   unsigned char* Bs = smem + A_BYTES;
 
@@ -194,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   const int kt_base = slab * p.ktiles_per_split;
   const int nkt = min((p.K + BK - 1) / BK - kt_base, p.ktiles_per_split);
   if (nkt <= 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
 
@@ -209,26 +242,33 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
   f32x4 ra[2][PA];      // DEEP: A pieces travel TWO tiles ahead (set it&1 holds tile it+1); W pieces always one (L2)
   u32x4 rw[PW];
   const int shift = (int)((unsigned)by * 7u % (unsigned)nkt);    // de-synchronise the panel sweeps of different rows
+  // this group's i-th K tile is tile i * KW + grp of the slab; past the end: a valid tile is fetched and stored as zeros
 #define KT_AT(i) (kt_base + (((i) + shift) >= nkt ? (i) + shift - nkt : (i) + shift))
+#define KG_AT(i) (KT_AT(min((i) * KW + grp, nkt - 1)) * BK)
+#define KLIM(i, src) ((KW == 1 || (i) * KW + grp < nkt) ? (src).K - (src).k0 : 0)
+#define A_LOAD(src, q) a_piece_load<BM, VEC>((src).P, (src).ld, p.M, (src).K, m0, (src).k0, q, tid)
+  const int nit = (nkt + KW - 1) / KW;
   {
-    const int k0 = KT_AT(0) * BK;
+    const int k0 = KG_AT(0);
+    const ASrc<DUAL> s0 = a_src<DUAL>(p, k0);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) ra[0][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k0, q);
+    for (int q = 0; q < PA; ++q) ra[0][q] = A_LOAD(s0, q);
 #pragma unroll
-    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q);
+    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q, tid);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[0][q], p.K - k0, q);
+    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[0][q], KLIM(0, s0), q, tid);
 #pragma unroll
-    for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q);
-    const int k1 = KT_AT(min(1, nkt - 1)) * BK, k2 = KT_AT(min(2, nkt - 1)) * BK;
+    for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q, tid);
+    const int k1 = KG_AT(1), k2 = KG_AT(2);
+    const ASrc<DUAL> s1 = a_src<DUAL>(p, k1), s2_ = a_src<DUAL>(p, k2);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) ra[0][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k1, q);
+    for (int q = 0; q < PA; ++q) ra[0][q] = A_LOAD(s1, q);
     if (DEEP) {
 #pragma unroll
-      for (int q = 0; q < PA; ++q) ra[1][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, k2, q);
+      for (int q = 0; q < PA; ++q) ra[1][q] = A_LOAD(s2_, q);
     }
 #pragma unroll
-    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q);
+    for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q, tid);
   }
   __syncthreads();
 
@@ -248,28 +288,33 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
       read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 1, af, bf);   /* second half: read before, multiplied after */     \
     }                                                                                                               \
     __syncthreads();                                   /* every wave has read tile IT */                            \
-    const int kcur = KT_AT(min((IT) + 1, nkt - 1)) * BK, kw = KT_AT(min((IT) + 2, nkt - 1)) * BK,                   \
-              ka = KT_AT(min((IT) + (DEEP ? 3 : 2), nkt - 1)) * BK;                                                 \
+    const int kcur = KG_AT((IT) + 1), kw = KG_AT((IT) + 2), ka = KG_AT((IT) + (DEEP ? 3 : 2));                      \
+    const ASrc<DUAL> scur = a_src<DUAL>(p, kcur), snext = a_src<DUAL>(p, ka);                                       \
+    const int klim = KLIM((IT) + 1, scur);                                                                          \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
-      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM>(As, ra[S][q], p.K - kcur, q);                         \
-      if (!(SPLIT_ABLATE & 1)) ra[S][q] = a_piece_load<BM, VEC>(p.A, p.lda, p.M, p.K, m0, ka, q);                   \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM>(As, ra[S][q], klim, q, tid);                          \
+      if (!(SPLIT_ABLATE & 1)) ra[S][q] = A_LOAD(snext, q);                                                         \
     }                                                                                                               \
     _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
-      if (!(SPLIT_ABLATE & 2) || (IT) == 0) w_piece_store<BN>(Bs, rw[q], q);                                        \
-      if (!(SPLIT_ABLATE & 1)) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, kw, q);                       \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) w_piece_store<BN>(Bs, rw[q], q, tid);                                   \
+      if (!(SPLIT_ABLATE & 1)) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, kw, q, tid);                  \
     }                                                                                                               \
     if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);                                                        \
     __syncthreads();                                   /* tile IT + 1 is visible */                                 \
   }
   if (DEEP) {
-    for (int it = 0; it < nkt; it += 2) {
+    for (int it = 0; it < nit; it += 2) {
       SPLIT_NT_TILE(0, it)
-      if (it + 1 < nkt) SPLIT_NT_TILE(1, it + 1)
+      if (it + 1 < nit) SPLIT_NT_TILE(1, it + 1)
     }
   } else {
-    for (int it = 0; it < nkt; ++it) SPLIT_NT_TILE(0, it)
+    for (int it = 0; it < nit; ++it) SPLIT_NT_TILE(0, it)
   }
 #undef SPLIT_NT_TILE
+#undef A_LOAD
+#undef KLIM
+#undef KG_AT
+#undef KT_AT
 
   if (EPI == 0 && (p.flags & FLAG_ATOMIC)) {
     // split-K: partial tile added into C (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
@@ -279,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (BN / 2) + j * 32 + li;
         if (col >= p.N) continue;
-        const float bv = (p.bias && slab == 0) ? p.bias[col] : 0.f;
+        const float bv = (p.bias && slab == 0 && grp == 0) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -288,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
       }
     return;
   }
-  // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip)
+  // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip); with KW groups each parks its partial
+  // tile in its own LDS image and the partials are summed group 0 first
   constexpr int CLD = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -299,21 +345,33 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
       for (int r = 0; r < 16; ++r)
         Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
   __syncthreads();
+  const float* C0 = reinterpret_cast<const float*>(smem_all);
+  constexpr int GSTRIDE = SMEM / 4;                   // floats between the partial tiles of consecutive groups
   if (EPI == 1) {
     // BasicLSTMCell gate math fused into the recurrent GEMM (model/model.py:110, TF BasicLSTMCell: gates i,j,f,o,
     // forget_bias 1).  The weight shadow is gate-interleaved (unreal_split_bf16x3 row_perm = 1): this block's 64
     // columns are hidden units u0..u0+15 of the four gates, so the tile holds everything one unit needs.
+    // FLAG_ACCUM: C holds the input-half pre-activations on entry (added after the product, as the chain does).
     const int u0 = bx * (BN / 4);
-    for (int id = threadIdx.x; id < BM * (BN / 4); id += 256) {
+    const bool add_pre = (p.flags & FLAG_ACCUM) != 0;
+    for (int id = threadIdx.x; id < BM * (BN / 4); id += 256 * KW) {
       const int r = id / (BN / 4), ul = id % (BN / 4);
       const int row = m0 + r, u = u0 + ul;
       if (row >= p.M) continue;
       float* pre = p.C + (size_t)row * p.ldc;
-      const float* cs = Cs + r * CLD + ul;
-      const float gi = 1.f / (1.f + expf(-((cs[0] + pre[u]) + p.bias[u])));
-      const float gj = tanhf((cs[BN / 4] + pre[256 + u]) + p.bias[256 + u]);
-      const float gf = 1.f / (1.f + expf(-((cs[2 * (BN / 4)] + pre[512 + u]) + p.bias[512 + u] + 1.0f)));
-      const float go = 1.f / (1.f + expf(-((cs[3 * (BN / 4)] + pre[768 + u]) + p.bias[768 + u])));
+      const float* cs = C0 + r * CLD + ul;
+      float s4[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float a = cs[g4 * (BN / 4)];
+#pragma unroll
+        for (int g = 1; g < KW; ++g) a += cs[g * GSTRIDE + g4 * (BN / 4)];
+        s4[g4] = add_pre ? a + pre[g4 * 256 + u] : a;
+      }
+      const float gi = 1.f / (1.f + expf(-(s4[0] + p.bias[u])));
+      const float gj = tanhf(s4[1] + p.bias[256 + u]);
+      const float gf = 1.f / (1.f + expf(-(s4[2] + p.bias[512 + u] + 1.0f)));
+      const float go = 1.f / (1.f + expf(-(s4[3] + p.bias[768 + u])));
       const float c = p.c_prev[(size_t)row * 256 + u] * gf + gi * gj;
       pre[u] = gi; pre[256 + u] = gj; pre[512 + u] = gf; pre[768 + u] = go;
       p.c_out[(size_t)row * 256 + u] = c;
@@ -325,11 +383,13 @@ __global__ __launch_bounds__(256, 2) void gemm_split_nt_kernel(SplitArgs p) {
                     (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
                     (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
   constexpr int CV = BN / 4;
-  for (int id = threadIdx.x; id < BM * CV; id += 256) {
+  for (int id = threadIdx.x; id < BM * CV; id += 256 * KW) {
     const int r = id / CV, c4 = (id % CV) * 4;
     const int row = m0 + r, col = n0 + c4;
     if (row >= p.M || col >= p.N) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+    f32x4 v = *reinterpret_cast<const f32x4*>(C0 + r * CLD + c4);
+#pragma unroll
+    for (int g = 1; g < KW; ++g) v += *reinterpret_cast<const f32x4*>(C0 + g * GSTRIDE + r * CLD + c4);
     float* cp = p.C + (size_t)row * p.ldc + col;
     if (vecC && col + 3 < p.N) {
       if (p.bias) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col); v += b4; }
@@ -557,6 +617,7 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   a.bias = bias; a.mask = mask; a.ldm = ldm; a.flags = flags;
   a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
+  a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.K1pad = 0;
   {
     const int nk = (K + BK - 1) / BK;
     if (splitk > nk) splitk = nk;
@@ -572,30 +633,49 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   } else {
     a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
-    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    // few tiles (the N = 256 products of a 4096-row step): KW wave groups share each tile's K range
+    const long tiles = (long)a.nbx * a.nby * a.splitk;
+    const int kw = (tiles <= 256 && a.ktiles_per_split >= 8) ? 4 : (tiles <= 512 && a.ktiles_per_split >= 4) ? 2 : 1;
+#define LAUNCH64(VEC_, KW_) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, VEC_, true, 0, KW_>), dim3(grid), \
+                                               dim3(256 * KW_), 0, (hipStream_t)stream, a)
+    if (a.vecA) { if (kw == 4) LAUNCH64(true, 4); else if (kw == 2) LAUNCH64(true, 2); else LAUNCH64(true, 1); }
+    else { if (kw == 4) LAUNCH64(false, 4); else if (kw == 2) LAUNCH64(false, 2); else LAUNCH64(false, 1); }
+#undef LAUNCH64
   }
   return unreal_launch_status();
 }
 
-int unreal_lstm_step_fwd(int rows, const float* h_prev, int ld_hprev, const uint16_t* Wh3, int ldw, long plane_stride,
-                         float* gates, const float* bias, const float* c_prev, float* c_out, float* h_out, int ld_h,
-                         void* stream) {
-  if (rows <= 0 || !h_prev || !Wh3 || !gates || !bias || !c_prev || !c_out || !h_out) return UNREAL_EINVAL;
-  if (ld_hprev < 256 || ld_h < 256 || ldw < 256 || (ldw & 7) || (plane_stride & 7) || plane_stride < 1024L * ldw ||
-      (((uintptr_t)Wh3) & 15))
+int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* h_prev, int ld_hprev, const uint16_t* W3,
+                         int ldw, long plane_stride, float* gates, const float* bias, const float* c_prev, float* c_out,
+                         float* h_out, int ld_h, void* stream) {
+  if (rows <= 0 || !h_prev || !W3 || !gates || !bias || !c_prev || !c_out || !h_out) return UNREAL_EINVAL;
+  const int kxpad = x ? (Kx + BK - 1) / BK * BK : 0;
+  if (x && (Kx <= 0 || ldx < Kx)) return UNREAL_EINVAL;
+  if (ld_hprev < 256 || ld_h < 256 || ldw < kxpad + 256 || (ldw & 7) || (plane_stride & 7) ||
+      plane_stride < 1024L * ldw || (((uintptr_t)W3) & 15))
     return UNREAL_EINVAL;
   SplitArgs a;
-  a.M = rows; a.N = 1024; a.K = 256;
-  a.A = h_prev; a.lda = ld_hprev; a.W = Wh3; a.ldw = ldw; a.plane = plane_stride; a.C = gates; a.ldc = 1024;
-  a.bias = bias; a.mask = nullptr; a.ldm = 0; a.flags = 0;
-  a.vecA = ((ld_hprev & 3) == 0) && ((((uintptr_t)h_prev) & 15) == 0);
+  a.M = rows; a.N = 1024; a.K = kxpad + 256;
+  a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = gates; a.ldc = 1024;
+  a.bias = bias; a.mask = nullptr; a.ldm = 0;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.ld_h = ld_h;
-  a.splitk = 1; a.ktiles_per_split = 256 / BK;
+  a.splitk = 1; a.ktiles_per_split = a.K / BK;
   a.nbx = 16; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
-  if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  const bool vec_h = ((ld_hprev & 3) == 0) && ((((uintptr_t)h_prev) & 15) == 0);
+  if (!x) {                              // gates holds the input-half pre-activations: the recurrent half is added
+    a.A = h_prev; a.lda = ld_hprev; a.A2 = nullptr; a.lda2 = 0; a.K1 = 256; a.K1pad = 0;
+    a.flags = FLAG_ACCUM;
+    a.vecA = vec_h;
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else {                               // [x | h_prev] @ the whole kernel in one product
+    a.A = x; a.lda = ldx; a.K1 = Kx; a.K1pad = kxpad; a.A2 = h_prev; a.lda2 = ld_hprev;
+    a.flags = 0;
+    a.vecA = vec_h && ((ldx & 3) == 0) && ldx >= 4 && ((((uintptr_t)x) & 15) == 0);
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return unreal_launch_status();
 }
 

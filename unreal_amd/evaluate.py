@@ -39,9 +39,9 @@ class Evaluate(object):
         done, returns, lengths, successes, timeouts = 0, [], [], 0, 0
         while done < n_episodes:
             ring.cur_idx(out=ws.frame_idx[:B])
-            net.encode_rows(ring, ws, 0, B, lar_from_ring=False, save_c1=False)
+            net.encode_rows(ring, ws, 0, B, lar_from_ring=False, save_c1=False, lstm_x=False)
             if net._use_lstm:
-                net.lstm_step(ws, 0, B)
+                net.lstm_step(ws, 0, B, fused_x=True)
             feat, ld = net.features(ws, 0)
             if not self.greedy:
                 self.draws.uniform(self.u)

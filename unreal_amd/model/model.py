@@ -202,6 +202,7 @@ class UnrealModel(object):
                 W = p["lstm_kernel"]
                 sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
                           lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1),   # gate-interleaved
+                          lstm_xh_fwd=ops.LstmKernelShadow(W, K_x),              # whole kernel, single-step launches
                           lstm_h_dgrad=S(W, 256, 1024, 1024, False, offset=K_x * 1024),
                           lstm_fc_dgrad=S(W, 256, 1024, 1024, False))
             if self._use_pixel_change:
@@ -267,10 +268,11 @@ class UnrealModel(object):
 
     # -- batched building blocks -----------------------------------------------------------------------
     def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
-                    objective_slot_offset=0, actor_ring=None, lar_prefilled=False):
+                    objective_slot_offset=0, actor_ring=None, lar_prefilled=False, lstm_x=True):
         """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
         rows [row0, row0+nrows) of a path workspace.  `objective_slot_offset` = -1 reproduces trainer.py:300, where the
-        bootstrap value is fed the objective of the previous frame's state."""
+        bootstrap value is fed the objective of the previous frame's state.  `lstm_x` False: a single time step follows
+        whose lstm_step(fused_x=True) multiplies [x | h] by the whole kernel, so the input half is not hoisted."""
         p = self.p
         idx = ws.frame_idx[row0:row0 + nrows]
         f2 = ws.f2[row0 * ops.F2_DIM:]
@@ -293,16 +295,23 @@ class UnrealModel(object):
             ops.lar_fill(nrows, A, ar.last_action, ar.last_reward, None, xcat, self.xld, clip=clip_lar)
         if self._objective_size:
             ops.objective_fill(ring, nrows, idx, xcat, self.xld, 256 + A + 1, slot_offset=objective_slot_offset)
-        ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
+        if lstm_x:
+            ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
 
-    def lstm_step(self, ws, t, B, b0=0, nrows=None):
-        """One BasicLSTMCell step for time row-block t (recurrent half of the gates + gate math); `b0`, `nrows`: only the
-        actors [b0, b0 + nrows) of the block."""
+    def lstm_step(self, ws, t, B, b0=0, nrows=None, fused_x=False):
+        """One BasicLSTMCell step for time row-block t; `b0`, `nrows`: only the actors [b0, b0 + nrows) of the block.
+        fused_x False: ws.gates holds the hoisted input half, the recurrent half + gate math run here; True (one step at
+        a time: rollout, bootstrap, batch-1 runners): [x | h] @ kernel in this one launch."""
         p = self.p
         n = B if nrows is None else nrows
         h_prev = ws.h0[b0 * 256:] if t == 0 else ws.h[((t - 1) * B + b0) * 256:]
         c_prev = ws.c0[b0 * 256:] if t == 0 else ws.c[((t - 1) * B + b0) * 256:]
         g_t = ws.gates[(t * B + b0) * 1024:]
+        if fused_x:
+            ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_xh_fwd"], g_t, p["lstm_bias"], c_prev,
+                              ws.c[(t * B + b0) * 256:], ws.h[(t * B + b0) * 256:],
+                              x=ws.xcat[(t * B + b0) * self.xld:], ldx=self.xld, Kx=self.K_x)
+            return
         ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[(t * B + b0) * 256:],
                           ws.h[(t * B + b0) * 256:])
 
@@ -315,10 +324,10 @@ class UnrealModel(object):
     def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False,
                       objective_slot_offset=0):
         """conv encoder -> fc -> (LSTM over T steps from ws.c0/ws.h0); rows = T*B listed in ws.frame_idx."""
-        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar, objective_slot_offset)
+        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar, objective_slot_offset, lstm_x=T > 1)
         if self._use_lstm:
             for t in range(T):
-                self.lstm_step(ws, t, B)
+                self.lstm_step(ws, t, B, fused_x=T == 1)
         return self.features(ws)
 
     def trunk_backward(self, ring, ws, gws, T, B, d_feat, h0_nonzero=False):

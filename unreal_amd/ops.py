@@ -341,10 +341,28 @@ class SplitWeights:
 
 def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, row_perm=0):
     _chk(src, "f32", (rows - 1) * ld_src + cols, "src")
-    orows = cols if transpose else rows
-    _chk(dst, "i16", 2 * plane + orows * ld_dst, "dst")
+    orows, ocols = (cols, rows) if transpose else (rows, cols)
+    _chk(dst, "i16", 2 * plane + (orows - 1) * ld_dst + ocols, "dst")
     _call("unreal_split_bf16x3", rows, cols, ptr(src), ld_src, int(bool(transpose)), int(row_perm), ptr(dst), ld_dst,
           plane)
+
+
+class LstmKernelShadow:
+    """Gate-interleaved bf16x3 shadow of the WHOLE BasicLSTMCell kernel [K_x + 256, 1024] as unreal_lstm_step_fwd(x=...)
+    multiplies it: planes[t][1024][pad32(K_x) + 256] -- input rows, zero padding to a K tile, recurrent rows."""
+
+    def __init__(self, kernel, K_x):
+        self.src, self.K_x, self.row_perm = kernel, K_x, 1
+        self.kxpad = (K_x + 31) // 32 * 32
+        self.N, self.K = 1024, self.kxpad + 256
+        self.ldw = self.K
+        self.plane = self.N * self.ldw
+        self.planes = torch.zeros(3 * self.plane, dtype=torch.int16, device=kernel.device)
+        self.refresh()
+
+    def refresh(self):
+        split_bf16x3(self.K_x, 1024, self.src, 1024, True, self.planes, self.ldw, self.plane, 1)
+        split_bf16x3(256, 1024, self.src[self.K_x * 1024:], 1024, True, self.planes[self.kxpad:], self.ldw, self.plane, 1)
 
 
 def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):
@@ -366,16 +384,20 @@ def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None):
     _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(colsum), splitk)
 
 
-def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256):
-    """One BasicLSTMCell step: gates (in: x-half pre-activations, out: activated gates) += h_prev @ Wh, gate math fused.
-    Wh: SplitWeights(kernel recurrent rows, transpose=True, row_perm=1)."""
-    if Wh.N != 1024 or Wh.K != 256 or Wh.row_perm != 1:
-        raise ValueError("lstm_step_fwd needs the gate-interleaved [1024,256] shadow of the recurrent kernel rows")
+def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256, x=None, ldx=0, Kx=0):
+    """One BasicLSTMCell step with the gate math fused into the product.
+    x None : gates (in: x-half pre-activations, out: activated gates) += h_prev @ Wh;
+             Wh = SplitWeights(kernel recurrent rows, transpose=True, row_perm=1).
+    x given: gates (out) = act([x | h_prev] @ kernel); Wh = LstmKernelShadow (gate-interleaved [1024, pad32(Kx) + 256])."""
+    kxpad = (Kx + 31) // 32 * 32 if x is not None else 0
+    if Wh.N != 1024 or Wh.K != kxpad + 256 or Wh.row_perm != 1:
+        raise ValueError("lstm_step_fwd needs the gate-interleaved [1024,%d] shadow of the LSTM kernel" % (kxpad + 256))
     _chk(h_prev, "f32", (rows - 1) * ld_hprev + 256, "h_prev"); _chk(gates, "f32", rows * 1024, "gates")
     _chk(bias, "f32", 1024, "bias"); _chk(c_prev, "f32", rows * 256, "c_prev"); _chk(c_out, "f32", rows * 256, "c_out")
     _chk(h_out, "f32", (rows - 1) * ld_h + 256, "h_out")
-    _call("unreal_lstm_step_fwd", rows, ptr(h_prev), ld_hprev, ptr(Wh.planes), Wh.ldw, Wh.plane, ptr(gates), ptr(bias),
-          ptr(c_prev), ptr(c_out), ptr(h_out), ld_h)
+    _chk(x, "f32", (rows - 1) * ldx + Kx if x is not None else None, "x", optional=True)
+    _call("unreal_lstm_step_fwd", rows, ptr(x), ldx, Kx, ptr(h_prev), ld_hprev, ptr(Wh.planes), Wh.ldw, Wh.plane,
+          ptr(gates), ptr(bias), ptr(c_prev), ptr(c_out), ptr(h_out), ld_h)
 
 
 def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):

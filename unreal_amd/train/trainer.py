@@ -232,9 +232,9 @@ class Trainer(object):
         if not prefilled:
             self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
         net.encode_rows(self.ring, ws, t * B, B, lar_from_ring=False, save_c1=ws.c1 is not None,
-                        lar_prefilled=prefilled and self.use_lstm)
+                        lar_prefilled=prefilled and self.use_lstm, lstm_x=False)
         if self.use_lstm:
-            net.lstm_step(ws, t, B)
+            net.lstm_step(ws, t, B, fused_x=True)
         feat, ld = net.features(ws, t * B)
         net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
 
@@ -285,9 +285,10 @@ class Trainer(object):
             b0, n = p["b0"], p["b1"] - p["b0"]
             r0 = t * B + b0
             p["ring"].cur_idx(out=ws.frame_idx[r0:r0 + n], base_actor=b0)
-            net.encode_rows(self.ring, ws, r0, n, lar_from_ring=False, save_c1=ws.c1 is not None, actor_ring=p["ring"])
+            net.encode_rows(self.ring, ws, r0, n, lar_from_ring=False, save_c1=ws.c1 is not None, actor_ring=p["ring"],
+                            lstm_x=False)
             if self.use_lstm:
-                net.lstm_step(ws, t, B, b0, n)
+                net.lstm_step(ws, t, B, b0, n, fused_x=True)
             feat, ld = net.features(ws, r0)
             net.policy_step(n, feat, ld, self.u_act[r0:r0 + n], self.pi[r0 * A:(r0 + n) * A], self.v[r0:r0 + n],
                             self.actions[r0:r0 + n])
