@@ -321,13 +321,20 @@ class UnrealModel(object):
             return ws.h[row0 * 256:], 256
         return ws.xcat[row0 * self.xld:], self.xld
 
+    # True: the input half of the gates of a T-step training sequence is one [T*B, K_x] x [K_x, 1024] product ahead of the
+    # recurrence and each step multiplies only h (the round-1 schedule).  False: every step multiplies [x | h] by the
+    # whole kernel -- at 4096 rows a step is bound by operand bytes, not FLOPs, and the hoisted form writes and re-reads
+    # 16 MB of pre-activations per step on top (measured: 52 -> 30 us per step of a sequence, tools/bench_kernels.py lstm).
+    hoist_lstm_x = False
+
     def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False,
                       objective_slot_offset=0):
         """conv encoder -> fc -> (LSTM over T steps from ws.c0/ws.h0); rows = T*B listed in ws.frame_idx."""
-        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar, objective_slot_offset, lstm_x=T > 1)
+        hoist = self.hoist_lstm_x and T > 1
+        self.encode_rows(ring, ws, 0, T * B, lar_from_ring, save_c1, clip_lar, objective_slot_offset, lstm_x=hoist)
         if self._use_lstm:
             for t in range(T):
-                self.lstm_step(ws, t, B, fused_x=T == 1)
+                self.lstm_step(ws, t, B, fused_x=not hoist)
         return self.features(ws)
 
     def trunk_backward(self, ring, ws, gws, T, B, d_feat, h0_nonzero=False):
