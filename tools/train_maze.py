@@ -24,11 +24,14 @@ ap.add_argument("--steps", type=float, default=2e7)
 ap.add_argument("--log-every", type=int, default=10)
 ap.add_argument("--lr-scale", type=float, default=1.0)
 ap.add_argument("--max-time-step", type=float, default=0)
+ap.add_argument("--entropy-beta", type=float, default=None, help="override options_lab's 0.001 (a stated deviation)")
 ap.add_argument("--out", default="")
 args = ap.parse_args()
 device = torch.device("cuda", 0)
 flags, net, tr = build_trainer(args, 0, 1, device)
 tr.initial_learning_rate *= args.lr_scale
+if args.entropy_beta is not None:
+    tr.entropy_beta = args.entropy_beta
 if args.max_time_step:
     tr.max_global_time_step = int(args.max_time_step)
 updates_total = tr.max_global_time_step / float(tr.Bg * flags.n_step_TD)
@@ -43,7 +46,7 @@ while not tr._full:
 torch.cuda.synchronize()
 t_fill = time.time() - t_fill
 out = open(args.out, "w") if args.out else None
-head = {"actors": args.actors, "groups": args.groups, "history": args.history, "lr0": tr.initial_learning_rate,
+head = {"actors": args.actors, "groups": args.groups, "entropy_beta": tr.entropy_beta, "history": args.history, "lr0": tr.initial_learning_rate,
         "max_time_step": tr.max_global_time_step, "replay_fill_s": round(t_fill, 1)}
 print(json.dumps(head), flush=True)
 if out:

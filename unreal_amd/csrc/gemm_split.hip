@@ -187,6 +187,20 @@ __device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x
 // DUAL (the LSTM step of a rollout): the A operand is the row-wise concatenation [A | A2] -- k < K1pad comes from A
 // (K1 valid columns, zero beyond), the rest from A2 -- multiplied by ONE weight shadow laid out the same way, so the
 // input half and the recurrent half of the gates are one product (BasicLSTMCell's own [x, h] @ kernel, model.py:110).
+#ifdef SPLIT_STAMPS      // diagnostic build only (tools/exp/lstm_step_stamps.py): where one workgroup's time goes
+__device__ unsigned long long g_split_stamps[8];
+#define SSTAMP(k)                                                                  \
+  do {                                                                             \
+    if (blockIdx.x == 9 && threadIdx.x == 0) {                                     \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                  \
+      g_split_stamps[k] += t_ - t_prev_;                                           \
+      t_prev_ = t_;                                                                \
+    }                                                                              \
+  } while (0)
+#else
+#define SSTAMP(k)
+#endif
+
 template <bool DUAL>
 struct ASrc { const float* P; int ld, K, k0; };
 
@@ -211,6 +225,9 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
   constexpr int C_BYTES = BM * (BN + 4) * 4;
   constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[KW * SMEM];
+#ifdef SPLIT_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = KW == 1 ? (int)threadIdx.x : (int)(threadIdx.x & 255);
   const int grp = KW == 1 ? 0 : (int)(threadIdx.x >> 8);
   unsigned char* smem = smem_all + grp * SMEM;
@@ -271,6 +288,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k1, q, tid);
   }
   __syncthreads();
+  SSTAMP(0);       // prologue: first tile fetched, split, stored; next tiles requested
 
   // One K tile.  Tile it+1 leaves register set S (split, LDS store) and tile it+3 is fetched into it, piece by piece,
   // next to the second-half MFMAs: loads spread between MFMAs keep the CU's vector-memory queue short (8 waves
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     for (int it = 0; it < nit; ++it) SPLIT_NT_TILE(0, it)
   }
 #undef SPLIT_NT_TILE
+  SSTAMP(1);       // K loop
 #undef A_LOAD
 #undef KLIM
 #undef KG_AT
@@ -345,6 +364,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
       for (int r = 0; r < 16; ++r)
         Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
   __syncthreads();
+  SSTAMP(2);       // partial tiles parked in LDS
   const float* C0 = reinterpret_cast<const float*>(smem_all);
   constexpr int GSTRIDE = SMEM / 4;                   // floats between the partial tiles of consecutive groups
   if (EPI == 1) {
@@ -354,11 +374,27 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     // FLAG_ACCUM: C holds the input-half pre-activations on entry (added after the product, as the chain does).
     const int u0 = bx * (BN / 4);
     const bool add_pre = (p.flags & FLAG_ACCUM) != 0;
-    for (int id = threadIdx.x; id < BM * (BN / 4); id += 256 * KW) {
+    constexpr int ITEMS = BM * (BN / 4) / (256 * KW);            // (row, unit) pairs per lane: 4 (64 x 64) or 8
+    // every global read of the epilogue is issued before the first gate is computed: C and c_prev may alias the
+    // outputs as far as the compiler knows, so left in the loop each pair would wait for its own loads in turn
+    float cprev[ITEMS], pre4[ITEMS][4];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+      const int id = threadIdx.x + e * 256 * KW;
+      const int row = min(m0 + id / (BN / 4), p.M - 1), u = u0 + id % (BN / 4);
+      cprev[e] = p.c_prev[(size_t)row * 256 + u];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) pre4[e][g4] = add_pre ? p.C[(size_t)row * p.ldc + g4 * 256 + u] : 0.f;
+    }
+    static_assert((256 * KW) % (BN / 4) == 0, "a lane keeps its hidden unit over the pairs it handles");
+    float bb[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) bb[g4] = p.bias[g4 * 256 + u0 + threadIdx.x % (BN / 4)];
+#pragma unroll
+    for (int e = 0; e < ITEMS; ++e) {
+      const int id = threadIdx.x + e * 256 * KW;
       const int r = id / (BN / 4), ul = id % (BN / 4);
       const int row = m0 + r, u = u0 + ul;
-      if (row >= p.M) continue;
-      float* pre = p.C + (size_t)row * p.ldc;
       const float* cs = C0 + r * CLD + (ul >> 4) * 64 + (ul & 15);      // 16 units x 4 gates per 64 columns
       float s4[4];
 #pragma unroll
@@ -366,17 +402,20 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         float a = cs[g4 * 16];
 #pragma unroll
         for (int g = 1; g < KW; ++g) a += cs[g * GSTRIDE + g4 * 16];
-        s4[g4] = add_pre ? a + pre[g4 * 256 + u] : a;
+        s4[g4] = add_pre ? a + pre4[e][g4] : a;
       }
-      const float gi = 1.f / (1.f + expf(-(s4[0] + p.bias[u])));
-      const float gj = tanhf(s4[1] + p.bias[256 + u]);
-      const float gf = 1.f / (1.f + expf(-(s4[2] + p.bias[512 + u] + 1.0f)));
-      const float go = 1.f / (1.f + expf(-(s4[3] + p.bias[768 + u])));
-      const float c = p.c_prev[(size_t)row * 256 + u] * gf + gi * gj;
+      const float gi = 1.f / (1.f + expf(-(s4[0] + bb[0])));
+      const float gj = tanhf(s4[1] + bb[1]);
+      const float gf = 1.f / (1.f + expf(-(s4[2] + bb[2] + 1.0f)));
+      const float go = 1.f / (1.f + expf(-(s4[3] + bb[3])));
+      const float c = cprev[e] * gf + gi * gj;
+      if (row >= p.M) continue;
+      float* pre = p.C + (size_t)row * p.ldc;
       pre[u] = gi; pre[256 + u] = gj; pre[512 + u] = gf; pre[768 + u] = go;
       p.c_out[(size_t)row * 256 + u] = c;
       p.h_out[(size_t)row * p.ld_h + u] = tanhf(c) * go;
     }
+    SSTAMP(3);     // gate math + stores issued
     return;
   }
   const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
@@ -673,7 +712,11 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
     a.A = x; a.lda = ldx; a.K1 = Kx; a.K1pad = kxpad; a.A2 = h_prev; a.lda2 = ld_hprev;
     a.flags = 0;
     a.vecA = vec_h && ((ldx & 3) == 0) && ldx >= 4 && ((((uintptr_t)x) & 15) == 0);
+#ifdef LSTM_FORCE_64
+    if (false) {
+#else
     if (a.vecA && rows >= 2048) {
+#endif
       // a full step (4096 rows): 128 x 128 tiles halve the operand bytes per flop (the 64 x 64 step moves 350 MB from
       // L2 for 13.7 GMAC); two wave groups share each tile's K range so that the 256 tiles still put 8 waves on a CU
       a.nbx = 8; a.nby = (rows + 127) / 128;
@@ -714,5 +757,17 @@ int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int tr
                      dst, ld_dst, plane_stride, row_perm);
   return unreal_launch_status();
 }
+
+#ifdef SPLIT_STAMPS
+int exp_split_read_stamps(unsigned long long* host8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_split_stamps), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_split_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 }  // extern "C"
