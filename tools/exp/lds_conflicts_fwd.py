@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""LDS-array cycles of encoder_fwd's wave-wide LDS accesses per frame, by the banking rules of MI355X_MICROARCH.md
+(lane groups per instruction, bank = (addr/4) mod 32 or 64; identical addresses broadcast).  Pure arithmetic, no GPU."""
+import collections
+
+G_B32 = [list(range(0, 32)), list(range(32, 64))]
+G_B128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+G_B128 += [[l + 32 for l in g] for g in G_B128]
+G_W64 = [list(range(16 * k, 16 * k + 16)) for k in range(4)]
+
+
+def cycles(addrs, groups, nbytes, banks):
+    """addrs[lane] byte address (None = inactive) -> LDS-array cycles: per group, max over banks of distinct dwords."""
+    tot = 0
+    for g in groups:
+        per_bank = collections.defaultdict(set)
+        for l in g:
+            a = addrs[l]
+            if a is None:
+                continue
+            for w in range(a // 4, (a + nbytes) // 4):
+                per_bank[w % banks].add(w)
+        tot += max((len(v) for v in per_bank.values()), default=0) if per_bank else 0
+    return tot
+
+
+def xrow(p, mode):
+    if mode == "cur":
+        return p ^ ((p >> 3) & 1)
+    return mode(p)
+
+
+FRB, XROW, XPL, FWD_X = 252, 32, 12800, 21504
+
+
+def conv1_reads(koff_fn=None, pix_base=None):
+    ideal = real = 0
+    for tt in range(25):
+        for kc in range(6):
+            for dw in range(2):
+                addrs = []
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    pos = tt * 16 + i
+                    k = 32 * kc + 8 * q
+                    a = (4 * (pos // 20)) * FRB + 12 * (pos % 20) + (k // 24) * FRB + k % 24 + 4 * dw
+                    addrs.append(a)
+                real += cycles(addrs, G_B32, 4, 32)
+                ideal += 2
+    return ideal, real
+
+
+def plane_writes(mode="cur"):
+    ideal = real = 0
+    for tt in range(25):
+        for u in range(3):
+            addrs = []
+            for lane in range(64):
+                i, q = lane & 15, lane >> 4
+                pos = tt * 16 + i
+                addrs.append(FWD_X + u * XPL + xrow(pos, mode) * XROW + 8 * q)
+            real += cycles(addrs, G_W64, 8, 32)
+            ideal += 4
+    return ideal, real
+
+
+def conv2_reads(mode="cur"):
+    ideal = real = 0
+    for kh in range(2):
+        for mt in range(6):
+            for c in range(4):
+                addrs = []
+                for lane in range(64):
+                    i, q = lane & 15, lane >> 4
+                    pos = min(16 * mt + i, 80)
+                    p1 = (2 * (pos // 9)) * 20 + 2 * (pos % 9)
+                    tap = 2 * (4 * kh + c) + (q >> 1)
+                    addrs.append(FWD_X + xrow(p1 + (tap >> 2) * 20 + (tap & 3), mode) * XROW + 16 * (q & 1))
+                r = cycles(addrs, G_B128, 16, 64)
+                real += 3 * r * 2          # 3 planes; 2 n-tile waves read the same
+                ideal += 3 * 4 * 2
+    return ideal, real
+
+
+if __name__ == "__main__":
+    for name, (i, r) in (("conv1 pixel reads (ds_read2_b32)", conv1_reads()), ("c1 plane writes (ds_write_b64)", plane_writes()),
+                         ("conv2 fragment reads (ds_read_b128)", conv2_reads())):
+        print("%-40s ideal %5d  with conflicts %5d LDS cycles per frame" % (name, i, r))

@@ -17,11 +17,17 @@ ap.add_argument("--steps", type=int, required=True)
 args = ap.parse_args()
 
 PER_STEP = {"encoder_bwd_kernel": 4, "encoder_fwd_kernel": 26, "pc_deconv_fwd_kernel": 2, "pc_deconv_bwd_kernel": 1,
-            "maze_step_kernel": 20, "gemm_split_tn_kernel": 11, "rmsprop_kernel": 1}
+            "maze_step_kernel": 20, "gemm_split_tn_kernel": 11, "rmsprop_kernel": 1,
+            # the NT kernel's instantiations are different kernels: big forward / dgrad products, the whole-kernel LSTM
+            # step, the 4096-row fc / BPTT dgrad steps
+            "gemm_split_nt_kernel<128, 128, true, false, 0, 1, false>": 11,
+            "gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>": 63,
+            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 80}
 
 
 def short(name):
-    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    return n if n.startswith("gemm_split_nt_kernel") else n.split("<")[0]
 
 
 out = {"_how": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps %d (tools/pmc_bench.sh; one "
