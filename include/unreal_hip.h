@@ -165,6 +165,13 @@ int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int tr
 int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* h_prev, int ld_hprev, const uint16_t* W3,
                          int ldw, long plane_stride, float* gates, const float* bias, const float* c_prev, float* c_out,
                          float* h_out, int ld_h, void* stream);
+/* BPTT through one recurrence step, fused: dh_rec = d_gates[rows,1024] (step t) * Wh^T on the split-operand path
+ * (Wh3 = natural-layout shadow of the kernel's recurrent rows, [256][1024]), and in the same launch the gate backward
+ * of step t-1 with dh = dh_above + dh_rec: dpre (d_gates of step t-1), dc_io in/out.  Same arithmetic and order as
+ * unreal_gemm_f32_split_nt followed by unreal_lstm_gates_bwd (bit-identical), without materialising dh_rec. */
+int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, int ldw, long plane_stride,
+                          const float* dh_above, float* dc_io, const float* gates_act, const float* c_prev,
+                          const float* c_new, float* dpre, void* stream);
 int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
                           float* c_out, float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,

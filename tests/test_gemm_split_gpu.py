@@ -63,6 +63,39 @@ def test_split_gemm_matches_fp64(M, N, K):
         ops.gemm_split_nt(M, N, K, dev(A), lda, W, Cx, ldc, splitk=2)                    # split-K needs ATOMIC
 
 
+@pytest.mark.parametrize("rows", [4096, 5000, 70, 3])
+def test_fused_bptt_step_is_the_two_kernel_path(rows):
+    """unreal_lstm_bptt_step == unreal_gemm_f32_split_nt (dh_rec = d_gates . Wh^T) + unreal_lstm_gates_bwd, bit for bit
+    (same tiles, same K dealing, same order of the element-wise arithmetic), and matches a float64 evaluation."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(rows)
+    Wh = rs.uniform(-0.07, 0.07, size=(256, 1024))
+    d_gates = rs.uniform(-1, 1, size=(rows, 1024)) * 1e-3
+    dh_above = rs.uniform(-1, 1, size=(rows, 256)) * 1e-2; dc0 = rs.uniform(-1, 1, size=(rows, 256)) * 1e-2
+    gates = rs.uniform(0.05, 0.95, size=(rows, 1024)); gates[:, 256:512] = rs.uniform(-0.9, 0.9, size=(rows, 256))
+    c_prev = rs.uniform(-2, 2, size=(rows, 256)); c_new = rs.uniform(-2, 2, size=(rows, 256))
+    sh = ops.SplitWeights(dev(Wh).view(-1), 256, 1024, 1024, False)
+    dgd, dha, gd, cpd, cnd = (dev(a).view(-1) for a in (d_gates, dh_above, gates, c_prev, c_new))
+    # two kernels
+    rec = torch.zeros(rows * 256, device=DEV); dc_a = dev(dc0).view(-1); dpre_a = torch.zeros(rows * 1024, device=DEV)
+    ops.gemm_split_nt(rows, 256, 1024, dgd, 1024, sh, rec, 256)
+    ops.lstm_gates_bwd(rows, dha, rec, dc_a, gd, cpd, cnd, dpre_a)
+    # fused
+    dc_b = dev(dc0).view(-1); dpre_b = torch.full((rows * 1024,), 9.0, device=DEV)
+    ops.lstm_bptt_step(rows, dgd, sh, dha, dc_b, gd, cpd, cnd, dpre_b)
+    assert torch.equal(dc_a, dc_b) and torch.equal(dpre_a, dpre_b)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    dh = f32(dh_above) + f32(d_gates) @ f32(Wh).T
+    i, j, f, o = (f32(gates[:, k * 256:(k + 1) * 256]) for k in range(4))
+    tc = np.tanh(f32(c_new))
+    dc = f32(dc0) + dh * o * (1 - tc * tc)
+    want = np.concatenate([dc * j * i * (1 - i), dc * i * (1 - j * j), dc * f32(c_prev) * f * (1 - f), dh * tc * o * (1 - o)], 1)
+    np.testing.assert_allclose(dpre_b.cpu().numpy().reshape(rows, 1024), want, atol=2e-8, rtol=2e-5)
+    np.testing.assert_allclose(dc_b.cpu().numpy().reshape(rows, 256), dc * f, atol=2e-8, rtol=2e-5)
+    with pytest.raises(ValueError):
+        ops.lstm_bptt_step(rows, dgd, ops.SplitWeights(dev(Wh).view(-1), 256, 1024, 1024, True), dha, dc_b, gd, cpd, cnd, dpre_b)
+
+
 @pytest.mark.parametrize("rows,A,obj", [(4096, 4, 0), (70, 3, 7), (3, 6, 0)])
 def test_whole_kernel_lstm_step_matches_hoisted_chain_and_fp64(rows, A, obj):
     """unreal_lstm_step_fwd(x=...) -- [x | h] @ kernel in one launch, as a rollout step runs it -- against (a) the

@@ -53,6 +53,8 @@ struct SplitArgs {
   const float* c_prev; float* c_out; float* h_out; int ld_h;
   // DUAL: A operand = [A (K1 valid columns, k < K1pad) | A2 (K - K1pad columns)]
   const float* A2; int lda2, K1, K1pad;
+  // fused BPTT step (EPI == 2): the product is dh_rec of the EARLIER time step, whose gate backward runs in the epilogue
+  const float* dh_above; float* dc_io; const float* gates_act; const float* c_new; float* dpre;     // c_prev: above
 };
 
 // One 16-byte piece of the A tile per call (piece p of ROWS*BK/1024).  Branch-free on purpose: rows past the end
@@ -418,6 +420,45 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     SSTAMP(3);     // gate math + stores issued
     return;
   }
+  if (EPI == 2) {
+    // BPTT through one BasicLSTMCell step, fused (unreal_lstm_bptt_step): this tile is dh_rec[row][u] = d_gates(t) . Wh^T
+    // for 64 hidden units u; with it the gate backward of step t-1 is purely element-wise -- same arithmetic, in the same
+    // order, as unreal_lstm_gates_bwd after the stand-alone product, so the two paths agree bit for bit.
+    constexpr int ITEMS = BM * BN / (256 * KW), CH = ITEMS < 4 ? ITEMS : 4;
+#pragma unroll
+    for (int e0 = 0; e0 < ITEMS; e0 += CH) {
+      float dha[CH], dcv[CH], cn[CH], cp[CH], ga[CH][4];
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {                   // all loads of the chunk first (outputs may alias for the compiler)
+        const int id = threadIdx.x + (e0 + e) * 256 * KW;
+        const size_t g = (size_t)min(m0 + id / BN, p.M - 1) * 256 + n0 + id % BN;
+        dha[e] = p.dh_above[g]; dcv[e] = p.dc_io[g]; cn[e] = p.c_new[g]; cp[e] = p.c_prev[g];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) ga[e][g4] = p.gates_act[(g / 256) * 1024 + g4 * 256 + g % 256];
+      }
+#pragma unroll
+      for (int e = 0; e < CH; ++e) {
+        const int id = threadIdx.x + (e0 + e) * 256 * KW;
+        const int r = id / BN, cidx = id % BN;
+        float rec = C0[r * CLD + cidx];
+#pragma unroll
+        for (int g = 1; g < KW; ++g) rec += C0[g * GSTRIDE + r * CLD + cidx];
+        if (m0 + r >= p.M) continue;
+        const size_t g = (size_t)(m0 + r) * 256 + n0 + cidx;
+        const float i = ga[e][0], j = ga[e][1], f = ga[e][2], o = ga[e][3];
+        const float dh = dha[e] + rec;
+        const float tc = tanhf(cn[e]);
+        const float dc = dcv[e] + dh * o * (1.f - tc * tc);
+        float* d = p.dpre + (g / 256) * 1024 + g % 256;
+        d[0] = dc * j * i * (1.f - i);
+        d[256] = dc * i * (1.f - j * j);
+        d[512] = dc * cp[e] * f * (1.f - f);
+        d[768] = dh * tc * o * (1.f - o);
+        p.dc_io[g] = dc * f;
+      }
+    }
+    return;
+  }
   const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
                     (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
                     (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
@@ -657,6 +698,7 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.K1pad = 0;
+  a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
   {
     const int nk = (K + BK - 1) / BK;
     if (splitk > nk) splitk = nk;
@@ -698,6 +740,7 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
   a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = gates; a.ldc = 1024;
   a.bias = bias; a.mask = nullptr; a.ldm = 0;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.ld_h = ld_h;
+  a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
   a.splitk = 1; a.ktiles_per_split = a.K / BK;
   a.nbx = 16; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
@@ -725,6 +768,30 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
     } else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
+  return unreal_launch_status();
+}
+
+int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, int ldw, long plane_stride,
+                          const float* dh_above, float* dc_io, const float* gates_act, const float* c_prev,
+                          const float* c_new, float* dpre, void* stream) {
+  if (rows <= 0 || !d_gates || !Wh3 || !dh_above || !dc_io || !gates_act || !c_prev || !c_new || !dpre) return UNREAL_EINVAL;
+  if (ldw < 1024 || (ldw & 7) || (plane_stride & 7) || plane_stride < 256L * ldw || (((uintptr_t)Wh3) & 15) ||
+      (((uintptr_t)d_gates) & 15))
+    return UNREAL_EINVAL;
+  SplitArgs a;
+  a.M = rows; a.N = 256; a.K = 1024;
+  a.A = d_gates; a.lda = 1024; a.W = Wh3; a.ldw = ldw; a.plane = plane_stride; a.C = nullptr; a.ldc = 256;
+  a.bias = nullptr; a.mask = nullptr; a.ldm = 0; a.flags = 0; a.vecA = 1;
+  a.c_prev = c_prev; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
+  a.A2 = nullptr; a.lda2 = 0; a.K1 = 1024; a.K1pad = 0;
+  a.dh_above = dh_above; a.dc_io = dc_io; a.gates_act = gates_act; a.c_new = c_new; a.dpre = dpre;
+  a.splitk = 1; a.ktiles_per_split = 1024 / BK;
+  a.nbx = 4; a.nby = (rows + 63) / 64;
+  const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
+  const long tiles = (long)a.nbx * a.nby;
+  if (tiles <= 256) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 4>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+  else if (tiles <= 512) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
 

@@ -326,6 +326,7 @@ class UnrealModel(object):
     # whole kernel -- at 4096 rows a step is bound by operand bytes, not FLOPs, and the hoisted form writes and re-reads
     # 16 MB of pre-activations per step on top (measured: 52 -> 30 us per step of a sequence, tools/bench_kernels.py lstm).
     hoist_lstm_x = False
+    fuse_bptt = True           # BPTT: recurrent dgrad + the earlier step's gate backward in one launch (lstm_bptt_step)
 
     def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False,
                       objective_slot_offset=0):
@@ -347,13 +348,24 @@ class UnrealModel(object):
             W = p["lstm_kernel"]
             Wh = W[K_x * 1024:]
             gws.dc.zero_()
-            for t in reversed(range(T)):
-                c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
-                ops.lstm_gates_bwd(B, d_feat[t * B * 256:], gws.dh_rec if t < T - 1 else None, gws.dc,
-                                   ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:],
-                                   gws.d_gates[t * B * 1024:])
-                if t > 0:
-                    ops.gemm_split_nt(B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, sh["lstm_h_dgrad"], gws.dh_rec, 256)
+            if self.fuse_bptt:
+                # the last step's gate backward stands alone; every earlier step's runs in the epilogue of the product
+                # that yields its dh_rec (one launch per step instead of two, dh_rec never written)
+                c_prev = ws.c0 if T == 1 else ws.c[(T - 2) * B * 256:]
+                ops.lstm_gates_bwd(B, d_feat[(T - 1) * B * 256:], None, gws.dc, ws.gates[(T - 1) * B * 1024:], c_prev,
+                                   ws.c[(T - 1) * B * 256:], gws.d_gates[(T - 1) * B * 1024:])
+                for t in reversed(range(1, T)):
+                    c_prev = ws.c0 if t == 1 else ws.c[(t - 2) * B * 256:]
+                    ops.lstm_bptt_step(B, gws.d_gates[t * B * 1024:], sh["lstm_h_dgrad"], d_feat[(t - 1) * B * 256:],
+                                       gws.dc, ws.gates[(t - 1) * B * 1024:], c_prev, ws.c[(t - 1) * B * 256:],
+                                       gws.d_gates[(t - 1) * B * 1024:])
+            else:                                      # the two-kernel form (bit-identical; kept for A/B timing)
+                for t in reversed(range(T)):
+                    c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
+                    ops.lstm_gates_bwd(B, d_feat[t * B * 256:], gws.dh_rec if t < T - 1 else None, gws.dc,
+                                       ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:], gws.d_gates[t * B * 1024:])
+                    if t > 0:
+                        ops.gemm_split_nt(B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, sh["lstm_h_dgrad"], gws.dh_rec, 256)
             dW = g["lstm_kernel"]
             # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
             # last_action_reward rows by the small-N outer-product kernel (no padded third tile)

@@ -416,6 +416,18 @@ def lstm_gates_bwd(rows, dh_above, dh_rec, dc_io, gates_act, c_prev, c_new, dpre
           ptr(c_new), ptr(dpre))
 
 
+def lstm_bptt_step(rows, d_gates, Wh, dh_above, dc_io, gates_act, c_prev, c_new, dpre):
+    """dh_rec = d_gates @ Wh^T and, in the same launch, the gate backward of the earlier step (dh = dh_above + dh_rec).
+    Wh: SplitWeights(kernel recurrent rows, transpose=False) -- [256, 1024]."""
+    if Wh.N != 256 or Wh.K != 1024 or getattr(Wh, "row_perm", 0):
+        raise ValueError("lstm_bptt_step needs the natural [256,1024] shadow of the recurrent kernel rows")
+    _chk(d_gates, "f32", rows * 1024, "d_gates"); _chk(dh_above, "f32", rows * 256); _chk(dc_io, "f32", rows * 256)
+    _chk(gates_act, "f32", rows * 1024); _chk(c_prev, "f32", rows * 256); _chk(c_new, "f32", rows * 256)
+    _chk(dpre, "f32", rows * 1024)
+    _call("unreal_lstm_bptt_step", rows, ptr(d_gates), ptr(Wh.planes), Wh.ldw, Wh.plane, ptr(dh_above), ptr(dc_io),
+          ptr(gates_act), ptr(c_prev), ptr(c_new), ptr(dpre))
+
+
 def linear_small_fwd(rows, K, NOUT, X, ldx, W, b, out, ldo):
     _chk(X, "f32", (rows - 1) * ldx + K); _chk(W, "f32", K * NOUT); _chk(b, "f32", NOUT)
     _chk(out, "f32", (rows - 1) * ldo + NOUT)
