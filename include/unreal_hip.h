@@ -29,6 +29,7 @@ extern "C" {
 #define UNREAL_GEMM_ACCUM 2
 #define UNREAL_GEMM_ATOMIC 4
 #define UNREAL_GEMM_RELU_MASK 8
+#define UNREAL_GEMM_RELU_BITS 16   /* split_nt only: mask = uint16 bit words (unreal_encoder_fwd relu_bits), ldm in words */
 
 /* ---- environment (environment/maze_environment.py:50-55,98-128; environment/environment.py:88-102;
  *      train/experience.py:63-93 add_frame; train/trainer.py:194-205,264-296 reset rules) ---------- */
@@ -120,7 +121,10 @@ int unreal_rollout_stats(int B, const int* n_steps, int* score_valid, const floa
 /* ---- conv encoder (model/model.py:281-289,786-787) and its gradient ------------------------------ */
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
                        const float* b1, const float* W2, const float* b2, float* c1_out /*nullable [N][400][16]*/,
-                       float* f2_out /*[N][2592]*/, void* stream);
+                       float* f2_out /*[N][2592]*/,
+                       uint16_t* relu_bits /*nullable [N][81][2]: bit c of word [n][pos][h] = f2[n][pos][16h + c] > 0,
+                                             i.e. bit (j % 16) of word j / 16 of row n; UNREAL_GEMM_RELU_BITS reads it */,
+                       void* stream);
 int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,
                        const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2, float* db2,
                        void* stream);
@@ -135,8 +139,10 @@ int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A,
  * at + n*ldw (ldw a multiple of 8 and >= K rounded up to 32, padding zero).  Same epilogue flags as
  * unreal_gemm_f32 except ATOMIC.  Used for the forward and dgrad GEMMs of the dense layers. */
 int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw,
-                             long plane_stride, float* C, int ldc, const float* bias, const float* mask, int ldm,
-                             int flags, int splitk, void* stream);
+                             long plane_stride, float* C, int ldc, const float* bias,
+                             const void* mask /* fp32 [M][ldm] (RELU_MASK: keep where > 0) or uint16 bit words [M][ldm]
+                                                 (RELU_BITS: keep column j where bit j % 16 of word j / 16 is set) */,
+                             int ldm, int flags, int splitk, void* stream);
 /* splitk > 1 needs UNREAL_GEMM_ATOMIC (K slabs added into a pre-initialised C with fp32 atomics; no ReLU / mask /
  * ACCUM then).  Measured at the per-step shapes (4096 rows): 4096x256x2592 61 -> 50 us at splitk 4, 4096x256x1024
  * slower (the atomics cost what the extra workgroups buy), so the trainer keeps splitk = 1 there. */

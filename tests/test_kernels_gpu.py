@@ -414,9 +414,23 @@ def test_encoder_fwd(ops, N, mode):
     close(c1.reshape(N, 20, 20, 16), h1, what="conv1")
     close(f2.reshape(N, 9, 9, 32), h2, what="conv2")
     f2b = torch.zeros(N * 2592, device=DEV)
+    bits = torch.full((N * 162,), -1, dtype=torch.int16, device=DEV)
     ops.encoder_fwd(dev(pool.reshape(-1)), dev(idx), scale, P["W_base_conv1"], P["b_base_conv1"],
-                    P["W_base_conv2"], P["b_base_conv2"], f2b, None)
+                    P["W_base_conv2"], P["b_base_conv2"], f2b, None, relu_bits=bits)
     assert torch.equal(f2, f2b)
+    # the 1-bit ReLU pattern: bit j % 16 of word j / 16 of a frame <=> f2[j] > 0 (what the fc dgrad masks with)
+    w = bits.cpu().numpy().view(np.uint16).reshape(N, 162).astype(np.uint32)
+    got = ((w[:, :, None] >> np.arange(16, dtype=np.uint32)[None, None, :]) & 1).reshape(N, 2592).astype(bool)
+    np.testing.assert_array_equal(got, f2.cpu().numpy().reshape(N, 2592) > 0)
+    # and the dgrad epilogue masks identically with the bits and with the fp32 activations
+    rs2 = np.random.RandomState(N + 7)
+    Wd = dev(rs2.uniform(-1, 1, size=2592 * 256), torch.float32)
+    sh = ops.SplitWeights(Wd, 2592, 256, 256, False)
+    d_fc = dev(rs2.uniform(-1, 1, size=N * 256), torch.float32)
+    a = torch.zeros(N * 2592, device=DEV); b = torch.zeros(N * 2592, device=DEV)
+    ops.gemm_split_nt(N, 2592, 256, d_fc, 256, sh, a, 2592, mask=f2, ldm=2592, flags=ops.GEMM_RELU_MASK)
+    ops.gemm_split_nt(N, 2592, 256, d_fc, 256, sh, b, 2592, mask=bits, ldm=162, flags=ops.GEMM_RELU_BITS)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
 
 
 @pytest.mark.parametrize("N", [1, 6, 131, 1100])     # 1100 > 512 workgroups: the grid-stride / prefetch path

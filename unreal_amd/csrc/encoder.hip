@@ -308,11 +308,13 @@ __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp
   }
 }
 
+template <bool BITS>
 __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
                                                              const int* __restrict__ frame_idx, float scale,
                                                              const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2,
-                                                             float* __restrict__ c1_out, float* __restrict__ f2_out) {
+                                                             float* __restrict__ c1_out, float* __restrict__ f2_out,
+                                                             uint16_t* __restrict__ relu_bits) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
   const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -417,13 +419,21 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     WG_BARRIER();     // [F2]
     if (!kh) {
       float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
+      uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
 #pragma unroll
       for (int mt = 0; mt < 6; ++mt) {
         const f32x4 part = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pos = 16 * mt + 4 * q + r;
-          if (pos < C2_POS) dst[pos * C2_CH] = fmaxf((acc[mt][r] + part[r]) + bias2, 0.f);
+          const float v = fmaxf((acc[mt][r] + part[r]) + bias2, 0.f);
+          if (pos < C2_POS) dst[pos * C2_CH] = v;
+          if (BITS) {
+            // ReLU pattern of the 16 channels this wave holds of 4 positions: ballot bit 16q + i = (position 4q + r of the
+            // tile, channel 16nt + i); the dgrad of the layer above reads 1 bit per element instead of the fp32 output
+            const unsigned long long m = __ballot(v > 0.f);
+            if (i == 0 && pos < C2_POS) bits_q[(16 * mt + r) * 2] = (uint16_t)(m >> (16 * q));
+          }
         }
       }
     }
@@ -760,11 +770,15 @@ extern "C" {
 
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
                        const float* b1, const float* W2, const float* b2, float* c1_out, float* f2_out,
-                       void* stream) {
+                       uint16_t* relu_bits, void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W1 || !b1 || !W2 || !b2 || !f2_out) return UNREAL_EINVAL;
   int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
-  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                     frame_scale, W1, b1, W2, b2, c1_out, f2_out);
+  if (relu_bits)
+    hipLaunchKernelGGL(encoder_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits);
+  else
+    hipLaunchKernelGGL(encoder_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits);
   return unreal_launch_status();
 }
 

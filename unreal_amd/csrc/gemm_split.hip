@@ -25,7 +25,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int ROW_B = 80;                    // bytes per LDS row: 32 bf16 + 16 pad
-constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_ATOMIC = 4, FLAG_RELU_MASK = 8;
+constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_ATOMIC = 4, FLAG_RELU_MASK = 8, FLAG_RELU_BITS = 16;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -459,6 +459,8 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     }
     return;
   }
+  // FLAG_RELU_BITS: mask is a bit matrix (uint16 words, row stride ldm words, bit j % 16 of word j / 16 = column j kept)
+  const uint16_t* mbits = reinterpret_cast<const uint16_t*>(p.mask);
   const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
                     (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
                     (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
@@ -483,6 +485,11 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = m4[e] > 0.f ? v[e] : 0.f;
       }
+      if (p.flags & FLAG_RELU_BITS) {                 // col is a multiple of 4: the four bits sit in one word
+        const unsigned w = mbits[(size_t)row * p.ldm + (col >> 4)] >> (col & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? v[e] : 0.f;
+      }
       *reinterpret_cast<f32x4*>(cp) = v;
     } else {
 #pragma unroll
@@ -492,6 +499,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         if (p.flags & FLAG_ACCUM) x += cp[e];
         if (p.flags & FLAG_RELU) x = fmaxf(x, 0.f);
         if (p.flags & FLAG_RELU_MASK) x = (p.mask[(size_t)row * p.ldm + col + e] > 0.f) ? x : 0.f;
+        if (p.flags & FLAG_RELU_BITS) x = ((mbits[(size_t)row * p.ldm + ((col + e) >> 4)] >> ((col + e) & 15)) & 1u) ? x : 0.f;
         cp[e] = x;
       }
     }
@@ -679,22 +687,23 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, c
 extern "C" {
 
 int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw, long plane_stride,
-                             float* C, int ldc, const float* bias, const float* mask, int ldm, int flags, int splitk,
+                             float* C, int ldc, const float* bias, const void* mask, int ldm, int flags, int splitk,
                              void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W3 || !C) return UNREAL_EINVAL;
   const int kpad = (K + BK - 1) / BK * BK;
   if (lda < K || ldw < kpad || (ldw & 7) || (plane_stride & 7) || plane_stride < (long)N * ldw || ldc < N ||
       (((uintptr_t)W3) & 15))
     return UNREAL_EINVAL;
-  if (flags & ~(FLAG_RELU | FLAG_ACCUM | FLAG_ATOMIC | FLAG_RELU_MASK)) return UNREAL_EINVAL;
+  if (flags & ~(FLAG_RELU | FLAG_ACCUM | FLAG_ATOMIC | FLAG_RELU_MASK | FLAG_RELU_BITS)) return UNREAL_EINVAL;
   if ((flags & FLAG_RELU_MASK) && (!mask || ldm < N)) return UNREAL_EINVAL;
-  if ((flags & FLAG_ATOMIC) && (flags & (FLAG_RELU | FLAG_RELU_MASK | FLAG_ACCUM))) return UNREAL_EINVAL;
+  if ((flags & FLAG_RELU_BITS) && (!mask || ldm < (N + 15) / 16 || (flags & FLAG_RELU_MASK))) return UNREAL_EINVAL;
+  if ((flags & FLAG_ATOMIC) && (flags & (FLAG_RELU | FLAG_RELU_MASK | FLAG_RELU_BITS | FLAG_ACCUM))) return UNREAL_EINVAL;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !(flags & FLAG_ATOMIC)) return UNREAL_EINVAL;
   SplitArgs a;
   a.M = M; a.N = N; a.K = K;
   a.A = A; a.lda = lda; a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = C; a.ldc = ldc;
-  a.bias = bias; a.mask = mask; a.ldm = ldm; a.flags = flags;
+  a.bias = bias; a.mask = static_cast<const float*>(mask); a.ldm = ldm; a.flags = flags;
   a.vecA = ((lda & 3) == 0) && lda >= 4 && ((((uintptr_t)A) & 15) == 0);
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.K1pad = 0;

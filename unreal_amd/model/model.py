@@ -92,6 +92,8 @@ class PathWS(object):
         self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
         self.c1 = f(rows * ops.C1_DIM) if save_c1 else None
         self.f2 = f(rows * ops.F2_DIM)
+        # ReLU pattern of f2, 1 bit per element (written by the encoder, read by the fc dgrad's epilogue instead of f2)
+        self.f2_bits = torch.zeros(rows * ops.RELU_WORDS, dtype=torch.int16, device=device) if save_c1 else None
         self.xcat = torch.zeros(rows * xld, dtype=torch.float32, device=device)
         if lstm:
             self.gates = f(rows * 1024)
@@ -278,8 +280,9 @@ class UnrealModel(object):
         f2 = ws.f2[row0 * ops.F2_DIM:]
         xcat = ws.xcat[row0 * self.xld:]
         c1 = ws.c1[row0 * ops.C1_DIM:] if (save_c1 and ws.c1 is not None) else None
+        bits = ws.f2_bits[row0 * ops.RELU_WORDS:] if (c1 is not None and ws.f2_bits is not None) else None
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
-                        p["W_base_conv2"], p["b_base_conv2"], f2, c1)
+                        p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits)
         sh = self.shadow
         ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
                           flags=ops.GEMM_RELU)
@@ -326,6 +329,7 @@ class UnrealModel(object):
     # whole kernel -- at 4096 rows a step is bound by operand bytes, not FLOPs, and the hoisted form writes and re-reads
     # 16 MB of pre-activations per step on top (measured: 52 -> 30 us per step of a sequence, tools/bench_kernels.py lstm).
     hoist_lstm_x = False
+    relu_bits = True           # fc dgrad masks with the encoder's 1-bit ReLU pattern instead of re-reading f2 (849 MB per branch)
     fuse_bptt = True           # BPTT: recurrent dgrad + the earlier step's gate backward in one launch (lstm_bptt_step)
 
     def trunk_forward(self, ring, ws, T, B, lar_from_ring=True, save_c1=True, clip_lar=False,
@@ -391,8 +395,12 @@ class UnrealModel(object):
             d_fc = d_feat
         ops.gemm_split_tn(2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256,
                               splitk=_splitk(2592, 256, rows), colsum=g["b_base_fc1"])
-        ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
-                          flags=ops.GEMM_RELU_MASK)
+        if ws.f2_bits is not None and self.relu_bits:
+            ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2_bits,
+                              ldm=ops.RELU_WORDS, flags=ops.GEMM_RELU_BITS)
+        else:
+            ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
+                              flags=ops.GEMM_RELU_MASK)
         ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,
                         g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
 

@@ -12,7 +12,8 @@ FRAME_BYTES = 21168
 PC_CELLS = 400
 F2_DIM = 2592
 C1_DIM = 6400
-GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC, GEMM_RELU_MASK = 1, 2, 4, 8
+GEMM_RELU, GEMM_ACCUM, GEMM_ATOMIC, GEMM_RELU_MASK, GEMM_RELU_BITS = 1, 2, 4, 8, 16
+RELU_WORDS = 162                      # uint16 words of ReLU bits per frame (2592 / 16)
 
 _DT = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64, "i16": torch.int16}
 
@@ -293,13 +294,15 @@ def reset_state(B, terminal_end, c, h):
 
 
 # ---- network -------------------------------------------------------------------------------------
-def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None):
+def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None, relu_bits=None):
+    """relu_bits: optional int16 [N * RELU_WORDS], bit (j % 16) of word j / 16 of a frame = f2[j] > 0."""
     N = frame_idx.numel()
     _chk(frames, "u8"); _chk(frame_idx, "i32", N)
     _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192); _chk(b2, "f32", 32)
     _chk(f2_out, "f32", N * F2_DIM); _chk(c1_out, "f32", N * C1_DIM, optional=True)
+    _chk(relu_bits, "i16", N * RELU_WORDS, "relu_bits", optional=True)
     _call("unreal_encoder_fwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W1), ptr(b1), ptr(W2), ptr(b2),
-          ptr(c1_out), ptr(f2_out))
+          ptr(c1_out), ptr(f2_out), ptr(relu_bits))
 
 
 def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2):
@@ -366,12 +369,16 @@ class LstmKernelShadow:
 
 
 def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):
-    """C = A[M,K] @ W[N,K]^T (fp32-grade, 3 x bf16 split operands on the bf16 matrix cores); W is a SplitWeights."""
+    """C = A[M,K] @ W[N,K]^T (fp32-grade, 3 x bf16 split operands on the bf16 matrix cores); W is a SplitWeights.
+    mask: fp32 [M, ldm] with GEMM_RELU_MASK, or int16 bit words [M, ldm] with GEMM_RELU_BITS (encoder_fwd relu_bits)."""
     if W.N != N or W.K != K:
         raise ValueError("split weights are [%d,%d], GEMM wants [%d,%d]" % (W.N, W.K, N, K))
     _chk(A, "f32", (M - 1) * lda + K, "A"); _chk(C, "f32", (M - 1) * ldc + N, "C")
     _chk(bias, "f32", N, "bias", optional=True)
-    _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
+    if flags & GEMM_RELU_BITS:
+        _chk(mask, "i16", (M - 1) * ldm + (N + 15) // 16, "mask bits")
+    else:
+        _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
     _call("unreal_gemm_f32_split_nt", M, N, K, ptr(A), lda, ptr(W.planes), W.ldw, W.plane, ptr(C), ldc, ptr(bias),
           ptr(mask), ldm, flags, splitk)
 
