@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 from bench import build_trainer
 from unreal_amd.model.model import UnrealModel
+from unreal_amd.train.trainer import Trainer
 
 names = [a for a in sys.argv[1:] if not a.startswith("-")]
 args = argparse.Namespace(actors=4096, history=int(os.environ.get("AB_HISTORY", 300)), groups=1)
@@ -28,6 +29,9 @@ def timed(k=6):
 
 timed(3)
 for name in names:
+    UnrealModel_ = UnrealModel
+    if name.startswith("Trainer."):
+        UnrealModel, name = Trainer, name[8:]
     base = getattr(UnrealModel, name)
     res = {base: [], (not base): []}
     for rnd in range(5):
@@ -39,3 +43,4 @@ for name in names:
     print("%s: default (%s) %.2f ms   flipped (%s) %.2f ms   [rounds %s | %s]" % (
         name, base, med[base], not base, med[not base], " ".join("%.2f" % x for x in res[base]),
         " ".join("%.2f" % x for x in res[not base])), flush=True)
+    UnrealModel = UnrealModel_
