@@ -22,7 +22,8 @@ PER_STEP = {"encoder_bwd_kernel": 4, "encoder_fwd_kernel": 26, "pc_deconv_fwd_ke
             # step, the 4096-row fc / BPTT dgrad steps
             "gemm_split_nt_kernel<128, 128, true, false, 0, 1, false>": 11,
             "gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>": 63,
-            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 80}
+            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 23,      # fc 2592 -> 256 of a 4096-row step
+            "gemm_split_nt_kernel<64, 64, true, true, 2, 4, false>": 57}      # fused BPTT step
 
 
 def short(name):
