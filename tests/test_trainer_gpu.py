@@ -420,3 +420,54 @@ def test_hostfed_indoor_objective_matches_oracle(B):
     # the objective rows of the LSTM kernel received gradient
     g = net.grads.shaped("lstm_kernel")[256 + 4:256 + 4 + OBJ]
     assert float(g.abs().max()) > 0
+
+
+def test_config1_long_horizon_drift_is_fp32_grade():
+    """SURVEY 8(d) asks that config 1's per-update losses track the restatement over a long run on identical draws.
+    120 consecutive updates of maze / FF / no aux / one actor: the device, the oracle in fp32 (the "CPU restatement") and
+    the oracle in fp64 (the arbiter) consume the SAME recorded Philox draws.  Trajectories (step counts, actions) must be
+    identical throughout; the device's distance from the fp64 arbiter -- losses and parameters -- must stay within a small
+    factor of the fp32 restatement's own distance from it (rounding differences are amplified by the training dynamics
+    alike for both: ~1e-2 relative on a loss near zero after 100 updates, measured with tools/exp/long_parity.py)."""
+    N, B, H, T = 120, 1, 30, 20
+    cfg = _cfg(False, False, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    net, applier, tr, draws = _build(cfg, B, seed=3)
+    named = net.export_named()
+    orcs, eds = {}, {}
+    for dt in (torch.float32, torch.float64):
+        eds[dt] = [ExplicitDraws()]
+        orcs[dt] = OracleTrainer(cfg, n_actors=B, draws=eds[dt], dtype=dt,
+                                 params={k: torch.tensor(v, dtype=dt) for k, v in named.items()})
+    while not tr._full:
+        tr.process(None, 0)
+    for dt in orcs:
+        eds[dt][0].action_u = [float(u[0]) for u in draws.log]
+        orcs[dt].fill()
+    g_t = 0
+    keys = ("policy_loss", "value_loss")
+    worst_dev = worst_o32 = 0.0
+    for it in range(N):
+        draws.log.clear()
+        steps, _ = tr.process(None, g_t)
+        ld = tr.last_losses
+        out = {}
+        for dt in orcs:
+            eds[dt][0].action_u = [float(x) for x in draws.log[0].reshape(-1)]
+            out[dt] = orcs[dt].process_batched(g_t)
+        s64, i64, l64 = out[torch.float64][0], out[torch.float64][1][0], out[torch.float64][2][0]
+        s32, i32 = out[torch.float32][0], out[torch.float32][1][0]
+        acts = list(tr.actions.cpu().numpy().reshape(-1)[:i64["n"]])
+        assert steps == s64 and acts == i64["actions"], "update %d: device trajectory left the arbiter's" % it
+        assert s32 == s64 and i32["actions"] == i64["actions"], "update %d: fp32 restatement left the arbiter's" % it
+        l32 = out[torch.float32][2][0]
+        d_dev = max(abs(ld[k] - float(l64[k])) / (1.0 + abs(float(l64[k]))) for k in keys)
+        d_o32 = max(abs(float(l32[k]) - float(l64[k])) / (1.0 + abs(float(l64[k]))) for k in keys)
+        p64 = {n: r.double().numpy().reshape(-1) for n, r in orcs[torch.float64].params.items()}
+        pd_dev = max(float(np.abs(net.p[n].cpu().double().numpy() - p64[n]).max()) for n in p64)
+        pd_o32 = max(float(np.abs(r.double().numpy().reshape(-1) - p64[n]).max()) for n, r in orcs[torch.float32].params.items())
+        worst_dev, worst_o32 = max(worst_dev, d_dev), max(worst_o32, d_o32)
+        assert d_dev <= 4.0 * max(worst_o32, 2e-6) + 1e-6, (it, d_dev, d_o32, worst_o32)
+        assert pd_dev <= 4.0 * max(pd_o32, 1e-7) + 1e-7, (it, pd_dev, pd_o32)
+        g_t += steps
+    assert worst_dev < 5e-2
