@@ -59,7 +59,12 @@ while global_t < args.steps:
         steps, episodes, score_sum = tr.read_stats()
         global_t += steps
         l = tr._publish_losses()
-        line = json.dumps({"global_t": global_t, "episodes": episodes,
+        rw = tr.rewards[:tr.Bg * flags.n_step_TD]          # the last group's rollout: what the policy currently does
+        live = tr.active_log[:tr.Bg * flags.n_step_TD].float()
+        n_live = float(live.sum().clamp(min=1))
+        bump = float(((rw < 0).float() * live).sum()) / n_live
+        goal = float(((rw > 0).float() * live).sum()) / n_live
+        line = json.dumps({"global_t": global_t, "episodes": episodes, "bump_rate": round(bump, 5), "goal_rate": round(goal, 6),
                            "mean_return": (score_sum / episodes) if episodes else None,
                            "total_loss": round(l["total_loss"], 4), "entropy": round(l["entropy"], 4),
                            "grad_norm": round(l["grad_norm"], 3), "steps_per_s": round(global_t / (time.time() - t0))})
