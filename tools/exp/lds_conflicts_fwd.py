@@ -86,3 +86,26 @@ if __name__ == "__main__":
     for name, (i, r) in (("conv1 pixel reads (ds_read2_b32)", conv1_reads()), ("c1 plane writes (ds_write_b64)", plane_writes()),
                          ("conv2 fragment reads (ds_read_b128)", conv2_reads())):
         print("%-40s ideal %5d  with conflicts %5d LDS cycles per frame" % (name, i, r))
+
+
+def search():
+    """brute force over row swizzles p ^ (bits a, b, c of p -> bits 0, 1, 2): conv2 read cycles (writes do not depend on it)"""
+    best = []
+    srcs = [None, 3, 4, 5, 6, 7, 8]
+    for a in srcs:
+        for b in srcs:
+            for c in srcs:
+                def f(p, a=a, b=b, c=c):
+                    g = (((p >> a) & 1) if a is not None else 0) | ((((p >> b) & 1) << 1) if b is not None else 0) | \
+                        ((((p >> c) & 1) << 2) if c is not None else 0)
+                    return p ^ g
+                i, r = conv2_reads(f)
+                best.append((r, a, b, c))
+    best.sort(key=lambda t: t[0])
+    print("ideal", i)
+    for t in best[:8]:
+        print("conv2 read cycles %d with p ^ (bit%s | bit%s<<1 | bit%s<<2)" % t)
+
+
+if __name__ == "__main__" and len(__import__("sys").argv) > 1:
+    search()

@@ -38,6 +38,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                             // 8 every block reads the same 8 rows of A (cache hits)
 #endif
 
+#ifndef SPLIT_ROW_DEAL
+#define SPLIT_ROW_DEAL 1    // 0: tile rows in lane order (tools/exp/ab_split_rows.py times both)
+#endif
+// Which tile row an 8-lane (A, ds_write_b64) or 4-lane (W, ds_write_b128) block stages.  A store instruction's lane
+// group covers two such blocks; with 80-byte LDS rows, rows r and r + 1 overlap in 4 of the 32 store banks (every store
+// 2-way conflicted: 13 % of the kernel's cycles were LDS conflict cycles, all from stores), rows r and r + 4 do not
+// (80 * 4 = 320 B = 16 banks past a multiple of 128 B).  So blocks 2m and 2m + 1 take rows (m, m + 4) of each 8 rows.
+__device__ __forceinline__ int row_deal(int j) {
+  return SPLIT_ROW_DEAL ? ((j & ~7) | ((j & 1) << 2) | ((j >> 1) & 3)) : j;
+}
+
 struct SplitArgs {
   int M, N, K;
   const float* A; int lda;
@@ -66,7 +77,7 @@ template <int ROWS, bool VEC>
 __device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int ld, int rows_total, int K, int r0, int k0, int p,
                                               int tid) {
   const int id = tid + 256 * p;
-  const int r = (SPLIT_ABLATE & 8) ? (id / (BK / 4)) & 7 : min(r0 + id / (BK / 4), rows_total - 1);
+  const int r = (SPLIT_ABLATE & 8) ? (id / (BK / 4)) & 7 : min(r0 + row_deal(id / (BK / 4)), rows_total - 1);
   const int k = k0 + (id % (BK / 4)) * 4;
   const float* row = P + (size_t)r * ld;
   if (VEC) return *reinterpret_cast<const f32x4*>(row + min(k, ld - 4));
@@ -111,7 +122,7 @@ __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float
 template <int ROWS>
 __device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p, int tid) {
   const int id = tid + 256 * p;
-  const int r = id / (BK / 4), k = (id % (BK / 4)) * 4;
+  const int r = row_deal(id / (BK / 4)), k = (id % (BK / 4)) * 4;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? v[e] : 0.f;
   u32x2 pl[3];
@@ -126,7 +137,7 @@ template <int ROWS>
 __device__ __forceinline__ u32x4 w_piece_load(const unsigned short* __restrict__ W, int ldw, long plane, int rows_total,
                                               int r0, int k0, int p, int tid) {
   const int id = tid + 256 * p;
-  const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
+  const int t = id / (ROWS * 4), r = row_deal((id / 4) % ROWS), c = id % 4;
   const int row = min(r0 + r, rows_total - 1);
   return *reinterpret_cast<const u32x4*>(W + t * plane + (size_t)row * ldw + k0 + c * 8);
 }
@@ -134,7 +145,7 @@ __device__ __forceinline__ u32x4 w_piece_load(const unsigned short* __restrict__
 template <int ROWS>
 __device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p, int tid) {
   const int id = tid + 256 * p;
-  const int t = id / (ROWS * 4), r = (id / 4) % ROWS, c = id % 4;
+  const int t = id / (ROWS * 4), r = row_deal((id / 4) % ROWS), c = id % 4;
   *reinterpret_cast<u32x4*>(S + (t * ROWS + r) * ROW_B + c * 16) = v;
 }
 
@@ -523,8 +534,26 @@ struct SplitTnArgs {
   int ntx, nty, splitk, ktiles_per_split;
 };
 
+// Thread -> (m4: which 4 columns of the 128, k4: which 4 k rows of the 32) of the TN tile it stages.  Lane order
+// (m4 = tid & 31, k4 = tid >> 5) leaves every ds_write_b64 2-way conflicted (a 16-lane store group spans 16 consecutive
+// m4 at one k4: rows 8 apart are 640 B = a multiple of the 128-byte store window; 28 % of the kernel's cycles were
+// conflict cycles).  Dealing tid bit 0 to k4 and bits 1-5 to m4 bits 0, 2, 3, 1, 4 makes a store group cover both 8-byte
+// halves, both row parities and four different swizzled chunks: 16 distinct slots.  A wave still reads two whole
+// 512-byte rows per load instruction.
+#ifndef SPLIT_TN_DEAL
+#define SPLIT_TN_DEAL 1
+#endif
+__device__ __forceinline__ int tn_m4() {
+  const int t = threadIdx.x;
+  return SPLIT_TN_DEAL ? (((t >> 1) & 1) | (((t >> 4) & 1) << 1) | (((t >> 2) & 3) << 2) | (((t >> 5) & 1) << 4)) : (t & 31);
+}
+__device__ __forceinline__ int tn_k4() {
+  const int t = threadIdx.x;
+  return SPLIT_TN_DEAL ? ((t & 1) | ((t >> 6) << 1)) : (t >> 5);
+}
+
 __device__ __forceinline__ void tn_piece_load(const float* __restrict__ P, int ld, int K, int c0, int k0, f32x4 (&reg)[4]) {
-  const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+  const int m4 = tn_m4(), k4 = tn_k4();
   const int col = min(c0 + 4 * m4, ld - 4);                 // columns past the matrix: pulled inside, never stored
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -535,7 +564,7 @@ __device__ __forceinline__ void tn_piece_load(const float* __restrict__ P, int l
 
 template <int ROWS>
 __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&reg)[4], int klim) {
-  const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+  const int m4 = tn_m4(), k4 = tn_k4();
   bool ok[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) ok[kk] = 4 * k4 + kk < klim;
@@ -553,7 +582,7 @@ __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&r
 
 // column sums of the B tile a thread holds (rows past K masked), weighted by w (0 or 1)
 __device__ __forceinline__ void tn_colsum_acc(const f32x4 (&reg)[4], int klim, float w, float (&cs)[4]) {
-  const int k4 = threadIdx.x >> 5;
+  const int k4 = tn_k4();
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     const float wk = (4 * k4 + kk < klim) ? w : 0.f;
@@ -629,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
 
   if (csw != 0.f) {      // block-uniform; the K loop ended with a barrier, so the operand LDS is free
     float* red = reinterpret_cast<float*>(smem);
-    const int m4 = threadIdx.x & 31, k4 = threadIdx.x >> 5;
+    const int m4 = tn_m4(), k4 = tn_k4();
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[k4 * BN + 4 * m4 + j] = cs[j];
     __syncthreads();
