@@ -118,20 +118,28 @@ def test_sampled_sequences_and_rp_triples(trained):
     cnt = ring.count.cpu().numpy().astype(np.int64)
     term = ring.r_terminal.cpu().numpy().reshape(B, H1)
     rew = ring.r_reward.cpu().numpy().reshape(B, H1)
-    seq = tr.seq_idx.cpu().numpy().reshape(L, B).astype(np.int64)          # the value-replay sample of the last call
-    ln = tr.seq_len.cpu().numpy()
-    assert ((ln >= 1) & (ln <= L)).all()
-    for b in range(0, B, 7):
-        idx = seq[:ln[b], b]
-        assert (idx // H1 == b).all()
-        slots = idx % H1
-        assert ((slots[1:] - slots[:-1]) % H1 == 1).all()                  # consecutive frames of this actor's ring
-        top = cnt[b] - H                                                   # oldest live absolute index
-        live = {(top + k) % H1 for k in range(H)}
-        assert set(slots.tolist()) <= live                                 # never the slot of the current observation
-        t_flags = term[b, slots]
-        assert not t_flags[:-1].any()                                      # stops at the first terminal, inclusive
-        assert ln[b] == L or t_flags[-1] == 1
+    # the samples of the last call: pixel-control and value-replay sequences (one batched pass), or the value-replay one
+    samples = list(zip(tr.seq_idx2, tr.seq_len2)) if getattr(tr, "batch_aux", False) else [(tr.seq_idx, tr.seq_len)]
+    for seq_t, len_t in samples:
+        seq = seq_t.cpu().numpy().reshape(L, B).astype(np.int64)
+        ln = len_t.cpu().numpy()
+        assert ((ln >= 1) & (ln <= L)).all()
+        for b in range(0, B, 7):
+            idx = seq[:ln[b], b]
+            assert (idx // H1 == b).all()
+            slots = idx % H1
+            assert ((slots[1:] - slots[:-1]) % H1 == 1).all()                  # consecutive frames of this actor's ring
+            top = cnt[b] - H                                                   # oldest live absolute index
+            live = {(top + k) % H1 for k in range(H)}
+            assert set(slots.tolist()) <= live                                 # never the slot of the current observation
+            t_flags = term[b, slots]
+            assert not t_flags[:-1].any()                                      # stops at the first terminal, inclusive
+            assert ln[b] == L or t_flags[-1] == 1
+    if getattr(tr, "batch_aux", False):
+        # the batched workspace lists sequence 2b = pixel-control sample of actor b, 2b + 1 = its value-replay sample
+        fi = tr.aux2_ws.frame_idx.cpu().numpy().reshape(T, B, 2)
+        for s_, (seq_t, _) in enumerate(samples):
+            np.testing.assert_array_equal(fi[:, :, s_], seq_t.cpu().numpy().reshape(L, B)[:T])
     rp = tr.rp_ws.frame_idx[:3 * B].cpu().numpy().reshape(B, 3).astype(np.int64)
     cls = tr.rp_class.cpu().numpy()
     assert (rp // H1 == np.arange(B)[:, None]).all()

@@ -106,8 +106,9 @@ class PathWS(object):
 class GradWS(object):
     """Gradient temporaries shared by all paths (sized for the largest)."""
 
-    def __init__(self, rows, B, device, lstm=True, pc=True, A=4):
+    def __init__(self, rows, B, device, lstm=True, pc=True, A=4, pc_rows=None):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
+        pc_rows = rows if pc_rows is None else pc_rows
         self.d_feat = f(rows * 256)
         self.d_fc = f(rows * 256)
         self.d_f2 = f(rows * ops.F2_DIM)
@@ -116,9 +117,10 @@ class GradWS(object):
             self.dh_rec = f(B * 256)
             self.dc = f(B * 256)
         if pc:
-            self.hp = f(rows * ops.F2_DIM)
-            self.d_dec = f(rows * ops.PC_CELLS * (1 + A))
-            self.pc_R = f(rows * ops.PC_CELLS)
+            self.hp = f(pc_rows * ops.F2_DIM)
+            self.d_hp = f(pc_rows * ops.F2_DIM) if pc_rows != rows else None      # else callers use d_f2
+            self.d_dec = f(pc_rows * ops.PC_CELLS * (1 + A))
+            self.pc_R = f(pc_rows * ops.PC_CELLS)
 
 
 def _splitk(M, N, K):

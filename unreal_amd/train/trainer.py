@@ -167,6 +167,13 @@ class Trainer(object):
         self.rp_ws = PathWS(3 * B, B, dev, save_c1=True, lstm=False, xld=xld) if self.use_reward_prediction else None
         rows = max(T, Ta if aux else 0, 3 if self.use_reward_prediction else 0) * B
         self.gws = GradWS(rows, B, dev, lstm=lstm, pc=self.use_pixel_change, A=A)
+        # pixel control and value replay as ONE batch of 2B replayed sequences (actor 2b = pc sample of b, 2b + 1 = vr
+        # sample): see _train_aux_batched
+        self.batch_aux = bool(self.batch_aux_default and self.use_pixel_change and self.use_value_replay)
+        if self.batch_aux:
+            self.aux2_ws = PathWS(Ta * 2 * B, 2 * B, dev, save_c1=True, lstm=lstm, xld=xld)
+            self.boot2_ws = PathWS(2 * B, 2 * B, dev, save_c1=False, lstm=lstm, xld=xld)
+            self.gws2 = GradWS(Ta * 2 * B, 2 * B, dev, lstm=lstm, pc=True, A=A, pc_rows=Ta * B)
         f = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
         i = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)
         d = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
@@ -190,6 +197,18 @@ class Trainer(object):
         if self.use_reward_prediction:
             self.rp_coin, self.rp_u, self.rp_class = i(B), d(B), i(B)
             self.rp_logits, self.rp_dlogits = f(B * 3), f(B * 3)
+        if self.batch_aux:
+            L = Ta + 1
+            self.seq_idx_cat = i(2 * L * B)
+            self.seq_idx2 = [self.seq_idx_cat[:L * B], self.seq_idx_cat[L * B:]]
+            self.seq_len2, self.seq_start2 = [i(B), i(B)], [i(B), i(B)]
+            self.seq_mask2 = [i(Ta * B), i(Ta * B)]
+            self.last2 = i(2 * B)
+            r = torch.arange(Ta * B, dtype=torch.int32)
+            self.map_seq = torch.stack([r, r + L * B], dim=1).reshape(-1).contiguous().to(dev)      # [2r + s] = s*L*B + r
+            b = torch.arange(B, dtype=torch.int32)
+            self.map_boot = torch.stack([b, b + B], dim=1).reshape(-1).contiguous().to(dev)          # [2b + s] = s*B + b
+            self.aux_dv = f(Ta * B)
         self.loss_sum = f(8)          # losses summed over the groups of one process() call
         self._fill_calls = 0
         self._full = False
@@ -442,6 +461,64 @@ class Trainer(object):
                              g["W_base_fc_v"], g["b_base_fc_v"])
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
 
+    batch_aux_default = True       # class default (tools/exp/ab_process.py rebuilds the trainer to compare)
+
+    def _train_aux_batched(self):
+        """[Pixel change] + [Value replay] (trainer.py:339-412) as ONE trunk pass over 2B replayed sequences: sequence
+        2b is actor b's pixel-control sample, 2b + 1 its value-replay sample, so a branch's rows are every other row of the
+        workspace (leading dimension doubled) and every trunk kernel -- encoder, fc, the T recurrent steps, their
+        backward -- runs once at twice the rows instead of twice.  Draws, sampling, targets, heads and losses are the
+        per-branch ones, in the reference's order (pc, vr)."""
+        B, Ta, A, net = self.Bg, self.local_t_max, self.action_size, self.local_network
+        p, g, gws, sh = net.p, net.g, self.gws2, net.shadow
+        L, rows = Ta + 1, Ta * B
+        for s in (0, 1):                                         # experience.sample_sequence(local_t_max + 1), pc then vr
+            self.draws.randint(self.experience_history_size - L - 1, self.seq_start2[s])
+            ops.replay_sample_seq(self.ring, L, self.seq_start2[s], self.seq_idx2[s], self.seq_len2[s])
+            ops.seq_last_idx(B, self.seq_idx2[s], self.seq_len2[s], self.last2[s * B:(s + 1) * B])
+            ops.seq_mask(B, Ta, self.seq_len2[s], self.seq_mask2[s])
+        # bootstrap frames of both samples (zero LSTM state, model.py:395,461)
+        bw = self.boot2_ws
+        ops.gather_i32(self.last2, self.map_boot, bw.frame_idx[:2 * B])
+        if self.use_lstm:
+            bw.c0.zero_()
+            bw.h0.zero_()
+        feat, ld = net.trunk_forward(self.ring, bw, 1, 2 * B, lar_from_ring=True, save_c1=False)
+        net.pc_head_forward(B, feat, 2 * ld, self.boot_hp)
+        ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
+                          p["b_pc_deconv_a"], qmax=self.boot_qmax)
+        ops.pc_returns(self.ring, L, self.seq_idx2[0], self.seq_len2[0], self.boot_qmax, self.gamma_pc, gws.pc_R)
+        net.value_forward(B, feat[ld:], 2 * ld, self.aux_boot_v)
+        ops.vr_returns(self.ring, L, self.seq_idx2[1], self.seq_len2[1], self.aux_boot_v, self.gamma, self.aux_R)
+        # the 2B sequences through the trunk
+        ws = self.aux2_ws
+        ops.gather_i32(self.seq_idx_cat, self.map_seq, ws.frame_idx[:2 * rows])
+        if self.use_lstm:
+            ws.c0.zero_()
+            ws.h0.zero_()
+        feat, ld = net.trunk_forward(self.ring, ws, Ta, 2 * B, lar_from_ring=True, save_c1=True)
+        d_feat = gws.d_feat
+        # pixel-control head on the even rows
+        net.pc_head_forward(rows, feat, 2 * ld, gws.hp)
+        ops.gather_i32(self.ring.r_action, self.seq_idx2[0][:rows], self.seq_act)
+        ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
+                          p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask2[0],
+                          lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
+                          loss=self.losses[3:4])
+        d_hp = gws.d_hp
+        ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
+        from ..model.model import _splitk
+        ops.gemm_split_tn(256, 2592, rows, feat, 2 * ld, d_hp, 2592, g["W_pc_fc1"], 2592,
+                          splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"])
+        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, sh["pc_fc1_dgrad"], d_feat, 2 * 256)
+        # value head on the odd rows
+        net.value_forward(rows, feat[ld:], 2 * ld, self.aux_v)
+        ops.vr_loss_grad(rows, self.aux_v, self.aux_R, self.seq_mask2[1], self.grad_scale, self.aux_dv, self.losses[4:5])
+        ops.linear_small_bwd(rows, 256, 1, feat[ld:], 2 * ld, self.aux_dv, 1, p["W_base_fc_v"], d_feat[256:], 2 * 256, False,
+                             g["W_base_fc_v"], g["b_base_fc_v"])
+        net.trunk_backward(self.ring, ws, gws, Ta, 2 * B, d_feat)
+
     def _train_rp(self):
         """[Reward prediction] (trainer.py:415-436, model.py:473-488, 569-576)."""
         B, net, ws = self.Bg, self.local_network, self.rp_ws
@@ -469,10 +546,13 @@ class Trainer(object):
         net.grads.flat.zero_()
         self.losses.zero_()
         self._train_base()
-        if self.use_pixel_change:
-            self._train_pc()
-        if self.use_value_replay:
-            self._train_vr()
+        if self.batch_aux and self.batch_aux_default:        # (the class attribute can be flipped at run time for A/B timing)
+            self._train_aux_batched()
+        else:
+            if self.use_pixel_change:
+                self._train_pc()
+            if self.use_value_replay:
+                self._train_vr()
         if self.use_reward_prediction:
             self._train_rp()
 
