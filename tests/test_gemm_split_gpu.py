@@ -96,7 +96,7 @@ def test_fused_bptt_step_is_the_two_kernel_path(rows):
         ops.lstm_bptt_step(rows, dgd, ops.SplitWeights(dev(Wh).view(-1), 256, 1024, 1024, True), dha, dc_b, gd, cpd, cnd, dpre_b)
 
 
-@pytest.mark.parametrize("rows,A,obj", [(4096, 4, 0), (70, 3, 7), (3, 6, 0)])
+@pytest.mark.parametrize("rows,A,obj", [(4096, 4, 0), (8200, 4, 0), (70, 3, 7), (3, 6, 0)])    # 8200: plain 128x128 tiles, ragged
 def test_whole_kernel_lstm_step_matches_hoisted_chain_and_fp64(rows, A, obj):
     """unreal_lstm_step_fwd(x=...) -- [x | h] @ kernel in one launch, as a rollout step runs it -- against (a) the
     chain it replaces (input-half GEMM, then the recurrent step) at the fp32 tolerance (the two differ only in the

@@ -802,7 +802,15 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
       // L2 for 13.7 GMAC); two wave groups share each tile's K range so that the 256 tiles still put 8 waves on a CU
       a.nbx = 8; a.nby = (rows + 127) / 128;
       const int grid128 = a.nbx * ((a.nby + 7) / 8 * 8);
-      hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>), dim3(grid128), dim3(512), 0, (hipStream_t)stream, a);
+#ifndef LSTM_BIG_KW
+#define LSTM_BIG_KW 1
+#endif
+      // more than one tile per CU (the 8192-row steps of the batched replay branches): plain 128 x 128 workgroups, two
+      // resident per CU, so one's gate epilogue runs beside the other's K loop
+      if (LSTM_BIG_KW == 1 && (long)a.nbx * a.nby > 256)
+        hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, false, 1, 1, true>), dim3(grid128), dim3(256), 0, (hipStream_t)stream, a);
+      else
+        hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>), dim3(grid128), dim3(512), 0, (hipStream_t)stream, a);
     } else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
@@ -827,8 +835,13 @@ int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, i
   a.nbx = 4; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
   const long tiles = (long)a.nbx * a.nby;
-  if (tiles <= 256) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 4>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
-  else if (tiles <= 512) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+#ifdef BPTT_FORCE_KW
+  const int kw = BPTT_FORCE_KW;
+#else
+  const int kw = tiles <= 256 ? 4 : tiles <= 512 ? 2 : 1;
+#endif
+  if (kw == 4) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 4>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+  else if (kw == 2) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 2, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
