@@ -16,14 +16,17 @@ ap.add_argument("outdir")
 ap.add_argument("--steps", type=int, required=True)
 args = ap.parse_args()
 
-PER_STEP = {"encoder_bwd_kernel": 4, "encoder_fwd_kernel": 26, "pc_deconv_fwd_kernel": 2, "pc_deconv_bwd_kernel": 1,
-            "maze_step_kernel": 20, "gemm_split_tn_kernel": 11, "rmsprop_kernel": 1,
+PER_STEP = {"encoder_bwd_kernel": 3, "encoder_fwd_kernel": 24, "pc_deconv_fwd_kernel": 2, "pc_deconv_bwd_kernel": 1,
+            "maze_step_kernel": 20, "gemm_split_tn_kernel": 8, "rmsprop_kernel": 1,
             # the NT kernel's instantiations are different kernels: big forward / dgrad products, the whole-kernel LSTM
-            # step, the 4096-row fc / BPTT dgrad steps
-            "gemm_split_nt_kernel<128, 128, true, false, 0, 1, false>": 11,
-            "gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>": 63,
-            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 23,      # fc 2592 -> 256 of a 4096-row step
-            "gemm_split_nt_kernel<64, 64, true, true, 2, 4, false>": 57}      # fused BPTT step
+            # step (4096-row rollout / bootstrap steps; 8192-row steps of the batched replay pass), the 4096-row fc, the
+            # fused BPTT steps (4096 rows: base; 8192 rows: replay pass)
+            "gemm_split_nt_kernel<128, 128, true, false, 0, 1, false>": 8,
+            "gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>": 22,
+            "gemm_split_nt_kernel<128, 128, true, false, 1, 1, true>": 20,
+            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 22,
+            "gemm_split_nt_kernel<64, 64, true, true, 2, 4, false>": 19,
+            "gemm_split_nt_kernel<64, 64, true, true, 2, 2, false>": 19}
 
 
 def short(name):
