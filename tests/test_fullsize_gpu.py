@@ -186,20 +186,20 @@ def _p64(net):
     return {k: torch.tensor(v, dtype=torch.float64) for k, v in net.export_named().items()}
 
 
-def _actor_rows(ws, ring, net, b, n, A):
-    """Frames (fp64, scaled) and last_action_reward columns of rows t*B + b, t < n, of a path workspace."""
-    rows = torch.arange(n, device=DEV) * B + b
+def _actor_rows(ws, ring, net, b, n, A, btot=None):
+    """Frames (fp64, scaled) and last_action_reward columns of rows t*btot + b, t < n, of a path workspace."""
+    rows = torch.arange(n, device=DEV) * (B if btot is None else btot) + b
     idx = ws.frame_idx[rows].long()
     x = ring.frames.view(-1, 84, 84, 3)[idx].cpu().double() * net.frame_scale
     lar = ws.xcat.view(-1, ws.xld)[rows, 256:256 + A + 1].cpu().double()
     return rows, x, lar
 
 
-def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what):
+def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what, btot=None):
     """conv2 output, fc, LSTM c / h of actor b's first n rows vs the oracle; returns (rows, features fp64)."""
     from oracle import model as M
     A = tr.action_size
-    rows, x, lar = _actor_rows(ws, tr.ring, net, b, n, A)
+    rows, x, lar = _actor_rows(ws, tr.ring, net, b, n, A, btot)
     _, h2 = M.encoder(x, p64)
     f = M.fc1(h2, p64)
     _close(ws.f2.view(-1, 2592)[rows], h2.reshape(n, 2592), 2e-5, 2e-5, what + " conv2")
@@ -377,3 +377,37 @@ def test_fullshape_value_replay_and_reward_prediction_rows_match_oracle(branches
         _close(tr.rp_logits.view(B, 3)[int(b)], logits.reshape(3), 2e-5, 2e-5, "rp logits")
     l = tr.losses.cpu().numpy()
     assert np.isfinite(l).all() and l[3] > 0 and l[4] > 0 and l[5] > 0
+
+
+def test_fullshape_batched_replay_pass_rows_match_oracle(branches):
+    """The product schedule: pixel control + value replay as one batch of 2B sequences (8192 rows per recurrent step,
+    163,840-row encoder / GEMM launches).  Rows of 32 actors' two sequences are recomputed by the fp64 oracle from the ring
+    frames and the weights: trunk (conv2 output, fc, LSTM c / h at the interleaved rows), the pixel-control fc output
+    and the value-replay V that the heads read through the doubled leading dimension."""
+    from oracle import model as M
+    flags, net, tr, actors, p64 = branches
+    if not tr.batch_aux:
+        pytest.skip("per-branch schedule")
+    tr._train_aux_batched()
+    torch.cuda.synchronize()
+    ws, gws, Ta = tr.aux2_ws, tr.gws2, tr.local_t_max
+    z = torch.zeros(256, dtype=torch.float64)
+    checked = 0
+    for b in actors[:32]:
+        for s_ in (0, 1):
+            mask = tr.seq_mask2[s_].view(Ta, B).cpu().numpy()
+            n = int(mask[:, b].sum())
+            if n == 0:
+                continue
+            rows2, feat = _check_trunk(net, tr, ws, 2 * int(b) + s_, n, z, z, p64, "sequence %d of actor %d" % (s_, b), btot=2 * B)
+            rows = torch.arange(n, device=DEV) * B + int(b)                 # the branch's own row numbering
+            if s_ == 0:
+                hp = torch.relu(feat @ p64["W_pc_fc1"] + p64["b_pc_fc1"])
+                _close(gws.hp.view(-1, 2592)[rows], hp, 2e-5, 2e-5, "pc fc (batched pass)")
+            else:
+                _, v = M.policy_value(feat, p64)
+                _close(tr.aux_v[rows], v, 5e-5, 5e-5, "value-replay V (batched pass)")
+            checked += n
+    assert checked > 32 * Ta
+    l = tr.losses.cpu().numpy()
+    assert np.isfinite(l).all() and l[3] > 0 and l[4] > 0
