@@ -378,31 +378,40 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
   for (int k = 0; k < 8; ++k) adbk[k] = 0.f;
   (void)adb;
   const int nt = gw & 1;
-  const int n_dd4 = PC_CELLS * CO / 4;           // f32x4 in one frame's d_dec
   const int qq = i >> 2, pp = i & 3;             // transposed reads: lane (4qq + pp) of a 16-lane group addresses block row qq
 
   const int stride = gridDim.x;
-  f32x4 pre_hp[HP_V], pre_dd[DD_V];
-
-  // scatter one frame's d_dec (registers, [400][CO] dense) into the planes + bias-gradient sums
-  auto stage_dd = [&](const f32x4 (&dd)[DD_V]) {
+  f32x4 pre_hp[HP_V];
+  // d_dec of a frame ([400][CO] fp32, dense): a thread owns output positions gtid and gtid + 256 -- CO consecutive floats
+  // each (a wave's loads cover one contiguous 64 * 4 * CO byte run), split into the three planes and stored as ONE 16-byte
+  // row per plane (channels >= CO zero).  The first form of this staging dealt f32x4 pieces to threads: a runtime
+  // division per element to find its position, three 2-byte LDS writes per element and eight compare-selects for the
+  // bias sums -- about as much VALU as the rest of the kernel.
+  float pre_dd[2][8];
+  auto load_dd = [&](int frame) {
+    const float* src = p.d_dec + (size_t)frame * PC_CELLS * CO;
 #pragma unroll
-    for (int c = 0; c < DD_V; ++c) {
-      const int id = gtid + 256 * c;
-      if (id < n_dd4) {
+    for (int h = 0; h < 2; ++h) {
+      const int pos = min(gtid + 256 * h, PC_CELLS - 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int el = 4 * id + e;
-          const int pos = el / CO, co = el - pos * CO;
-          const float v = dd[c][e];
-          unsigned short t[3];
-          split1p(v, t);
+      for (int co = 0; co < 8; ++co) pre_dd[h][co] = (co < CO) ? src[pos * CO + co] : 0.f;
+    }
+  };
+  auto stage_dd = [&]() {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            reinterpret_cast<unsigned short*>(ddp + pl * DDP_PLANE + pos * DDP_ROW)[co] = t[pl];
+    for (int h = 0; h < 2; ++h) {
+      const int pos = gtid + 256 * h;
+      if (pos < PC_CELLS) {
+        u32x2p lo[3], hi[3];
+        split4p((f32x4){pre_dd[h][0], pre_dd[h][1], pre_dd[h][2], pre_dd[h][3]}, lo);
+        split4p((f32x4){pre_dd[h][4], pre_dd[h][5], pre_dd[h][6], pre_dd[h][7]}, hi);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) adbk[k] += (co == k) ? v : 0.f;
+        for (int pl = 0; pl < 3; ++pl) {
+          typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<u32x4p*>(ddp + pl * DDP_PLANE + pos * DDP_ROW) = (u32x4p){lo[pl][0], lo[pl][1], hi[pl][0], hi[pl][1]};
         }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) adbk[k] += pre_dd[h][k];
       }
     }
   };
@@ -413,13 +422,8 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
       hp_store_planes(hpp, gtid, pre_hp);
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(p.d_dec + (size_t)n0 * PC_CELLS * CO);
-#pragma unroll
-      for (int c = 0; c < DD_V; ++c) {
-        int id = gtid + 256 * c;
-        pre_dd[c] = s4[id < n_dd4 ? id : 0];
-      }
-      stage_dd(pre_dd);
+      load_dd(n0);
+      stage_dd();
     }
   }
   for (int base = blockIdx.x; base < p.N; base += stride) {
@@ -430,12 +434,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     __syncthreads();  // [S0] hp / d_dec planes of frame n staged; dhs drained
     if (has_next) {
       hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre_hp);
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(p.d_dec + (size_t)nn * PC_CELLS * CO);
-#pragma unroll
-      for (int c = 0; c < DD_V; ++c) {
-        int id = gtid + 256 * c;
-        pre_dd[c] = s4[id < n_dd4 ? id : 0];
-      }
+      load_dd(nn);
     }
     if (valid) {
       // (a) dgrad: wave gw owns position tiles (gw>>1) + 2jj (jj = 0..2) and channel half nt
@@ -509,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     }
     if (has_next) {
       hp_store_planes(hpp, gtid, pre_hp);
-      stage_dd(pre_dd);
+      stage_dd();
     }
   }
 
