@@ -20,19 +20,34 @@ from .. import ops
 
 # The simulators' frames reach the pinned staging by a host memcpy of 21 KB per actor and step -- the largest host
 # cost of the path.  It is cut into row blocks copied by a few threads (torch's copy releases the GIL).
-_COPY_THREADS = max(1, min(8, (os.cpu_count() or 1) // 2))
+# UNREAL_COPY_THREADS overrides the count (default: up to 8; a GPU's share of the host is 16 cores on the test boxes).
+_COPY_THREADS = int(os.environ.get("UNREAL_COPY_THREADS", 0)) or max(1, min(8, (os.cpu_count() or 1) // 2))
 _COPY_POOL = ThreadPoolExecutor(_COPY_THREADS) if _COPY_THREADS > 1 else None
+_COPY_IMPL = os.environ.get("UNREAL_COPY_IMPL", "numpy")
 
 
 def _stage_frames(dst, frames):
-    """dst (pinned uint8 [n,84,84,3]) <- frames (numpy uint8 [n,84,84,3]), in parallel row blocks."""
-    src = torch.from_numpy(np.ascontiguousarray(frames))
+    """dst (pinned uint8 [n,84,84,3]) <- frames (numpy uint8 [n,84,84,3]), in parallel row blocks.
+    Plain memcpy per block (numpy releases the GIL): torch's copy_ starts its own intra-op team inside every pool
+    thread, and 8 pool threads x that team ran at a third of the rate of 2 (UNREAL_COPY_IMPL=torch restores it)."""
     n = dst.shape[0]
+    if _COPY_IMPL == "torch":
+        src = torch.from_numpy(np.ascontiguousarray(frames))
+        if _COPY_POOL is None or n < 4 * _COPY_THREADS:
+            dst.copy_(src)
+            return
+        step = (n + _COPY_THREADS - 1) // _COPY_THREADS
+        futs = [_COPY_POOL.submit(dst[a:a + step].copy_, src[a:a + step]) for a in range(0, n, step)]
+        for f in futs:
+            f.result()
+        return
+    d = dst.numpy()
+    src = np.asarray(frames)
     if _COPY_POOL is None or n < 4 * _COPY_THREADS:
-        dst.copy_(src)
+        np.copyto(d, src)
         return
     step = (n + _COPY_THREADS - 1) // _COPY_THREADS
-    futs = [_COPY_POOL.submit(dst[a:a + step].copy_, src[a:a + step]) for a in range(0, n, step)]
+    futs = [_COPY_POOL.submit(np.copyto, d[a:a + step], src[a:a + step]) for a in range(0, n, step)]
     for f in futs:
         f.result()
 
