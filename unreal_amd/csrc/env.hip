@@ -128,35 +128,55 @@ struct StepArgs {
 
 __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   __shared__ uint4 wall_img[FRAME_BYTES / 16];
+  // the workgroup's actors' scalar state, fetched by one thread per actor while the wall image is built: read inside the
+  // per-actor loop, each actor would start with two dependent global round trips (state, then the previous slot's terminal
+  // flag) that nothing overlaps -- 8 actors x ~2 us of a 38 us launch
+  __shared__ int s_flag[kActorsPerGroup], s_x[kActorsPerGroup], s_y[kActorsPerGroup], s_a[kActorsPerGroup],
+      s_cnt[kActorsPerGroup], s_la[kActorsPerGroup], s_prev[kActorsPerGroup];
+  __shared__ float s_lr[kActorsPerGroup], s_ep[kActorsPerGroup];
+  if (threadIdx.x < kActorsPerGroup) {
+    const int k = threadIdx.x, b = blockIdx.x * kActorsPerGroup + k;
+    if (b < p.B) {
+      const int cnt = p.count[b];
+      s_flag[k] = p.active_rw ? p.active_rw[b] : (p.active ? p.active[b] : 1);
+      s_x[k] = p.pos[2 * b]; s_y[k] = p.pos[2 * b + 1];
+      s_a[k] = p.actions[b];
+      s_cnt[k] = cnt;
+      s_la[k] = p.last_action[b];
+      s_lr[k] = p.last_reward[b];
+      s_ep[k] = p.track_score ? p.episode_reward[b] : 0.f;
+      s_prev[k] = cnt > 0 ? p.r_terminal[(size_t)b * p.H1 + (cnt - 1) % p.H1] : 0;
+    }
+  }
   build_wall_image(wall_img);
   __syncthreads();
   const int H1 = p.H1;
   for (int k = 0; k < kActorsPerGroup; ++k) {
     const int b = blockIdx.x * kActorsPerGroup + k;
     if (b >= p.B) break;
-    const int act_flag = p.active_rw ? p.active_rw[b] : (p.active ? p.active[b] : 1);
+    const int act_flag = s_flag[k];
     if (p.active_rw && threadIdx.x == 0) p.active_log_t[b] = act_flag;
     if (!act_flag) {
       // idle for the rest of the rollout: its observation and last action / reward stay what they are
       if (threadIdx.x == 0) {
-        if (p.next_idx) p.next_idx[b] = b * H1 + p.count[b] % H1;
+        if (p.next_idx) p.next_idx[b] = b * H1 + s_cnt[k] % H1;
         if (p.next_lar) {
           float* row = p.next_lar + (size_t)b * p.lar_ld + p.lar_col0;
-          const int la0 = p.last_action[b];
+          const int la0 = s_la[k];
           for (int e = 0; e < p.A; ++e) row[e] = (e == la0) ? 1.f : 0.f;
-          row[p.A] = p.last_reward[b];
+          row[p.A] = s_lr[k];
         }
       }
       continue;
     }
-    const int x = p.pos[2 * b], y = p.pos[2 * b + 1];
-    const int a = p.actions[b];
-    const int cnt = p.count[b];
-    const int la = p.last_action[b];
-    const float lr = p.last_reward[b];
+    const int x = s_x[k], y = s_y[k];
+    const int a = s_a[k];
+    const int cnt = s_cnt[k];
+    const int la = s_la[k];
+    const float lr = s_lr[k];
     const int slot = cnt % H1;
-    const int prev_term = cnt > 0 ? p.r_terminal[(size_t)b * H1 + (cnt - 1) % H1] : 0;
-    float ep = p.track_score ? p.episode_reward[b] : 0.f;
+    const int prev_term = s_prev[k];
+    float ep = s_ep[k];
 
     // _move (maze_environment.py:76-91)
     int dx = (a == 3) - (a == 2), dy = (a == 1) - (a == 0);
