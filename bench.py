@@ -147,8 +147,7 @@ def main():
     while not tr._full:                      # replay warm-up: untimed, global_t frozen
         tr.process(None, 0)
         k += 1
-        if k % 50 == 0:                      # bound the queue of un-synchronised dispatches: rocprofv3 --pmc segfaults
-            torch.cuda.synchronize()         # in its own thread when ~24 k launches are queued at once (r02_pmc_fault.log)
+        # (Trainer._fill_experience bounds the un-synchronised dispatch queue itself: one stream sync every 64 calls)
         if k in (1, 2, 10, 100, 1000):
             mark("fill call %d" % k)
     torch.cuda.synchronize()

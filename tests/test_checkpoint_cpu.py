@@ -65,3 +65,24 @@ def test_round_trip_and_rotation(tmp_path):
     ck.import_npz(p, net4)
     for n, _, _ in net.spec:
         assert torch.equal(net4.params.views[n], net.params.views[n])
+
+
+def test_unrelated_files_are_ignored_and_malformed_ones_raise(tmp_path):
+    """A stray best.pt / another run's prefix must not abort a periodic save (the reference's Saver ignores unrelated
+    files, main.py:356-427); a file that carries OUR prefix with a malformed tail still raises."""
+    import pytest
+    d = str(tmp_path / "ckpt")
+    net, app = _Net(), _Applier()
+    app._create_slots(net.params.flat)
+    os.makedirs(d)
+    for stray in ("best.pt", "exported-model.pt", "other-12-300.pt"):
+        open(os.path.join(d, stray), "wb").write(b"x")
+    with pytest.warns(UserWarning):
+        ck.save(d, net, app, global_t=100, wall_t=1.0)
+    with pytest.warns(UserWarning):
+        assert [t for t, _ in ck.list_checkpoints(d)] == [100]
+        assert ck.restore(d, _Net(), _Applier())[0] == 100
+    ck.save(d, net, app, global_t=300, wall_t=2.0, name="other")           # 'other-12-300.pt' is that run's own family
+    open(os.path.join(d, "checkpoint-final.pt"), "wb").write(b"x")
+    with pytest.raises(ValueError):
+        ck.list_checkpoints(d)

@@ -388,6 +388,7 @@ def test_fullshape_batched_replay_pass_rows_match_oracle(branches):
     flags, net, tr, actors, p64 = branches
     if not tr.batch_aux:
         pytest.skip("per-branch schedule")
+    net.grads.flat.zero_()                       # what the pass leaves in net.g is its own contribution (checked below)
     tr._train_aux_batched()
     torch.cuda.synchronize()
     ws, gws, Ta = tr.aux2_ws, tr.gws2, tr.local_t_max
@@ -411,3 +412,92 @@ def test_fullshape_batched_replay_pass_rows_match_oracle(branches):
     assert checked > 32 * Ta
     l = tr.losses.cpu().numpy()
     assert np.isfinite(l).all() and l[3] > 0 and l[4] > 0
+
+
+def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
+    """Backward of the product's replay schedule at production shape (runs after the test above: net.g holds exactly the
+    batched pass's contribution, its operands are live in aux2_ws / gws2): pixel-control deconv dgrad + wgrad on every
+    other row of the 2B-sequence batch, the pc fc wgrad read through the doubled leading dimension, the 163,840-row fc1
+    wgrad (split-K TN, K = 163,840) / dgrad and the 163,840-frame encoder_bwd -- each against an fp64 evaluation on the
+    device from the same live operands.  Tolerance: 2e-4 of the largest element, the bar of the small-shape tests."""
+    import torch.nn.functional as F
+    flags, net, tr, actors, p64 = branches
+    if not tr.batch_aux:
+        pytest.skip("per-branch schedule")
+    ws, gws, ring, A, Ta = tr.aux2_ws, tr.gws2, tr.ring, tr.action_size, tr.local_t_max
+    rows, rows2 = Ta * B, 2 * Ta * B
+    g = net.g
+    # ---- pixel-control head: d_dec -> d_hp (dgrad, ReLU of the fc), dW / db of both deconvs --------------------------
+    hp = gws.hp[:rows * 2592].view(rows, 2592)
+    d_dec = gws.d_dec[:rows * 400 * (1 + A)].view(rows, 400, 1 + A)
+    d_hp = gws.d_hp[:rows * 2592].view(rows, 2592)
+    Wv = net.params.shaped("W_pc_deconv_v").double().permute(3, 2, 0, 1)          # [32,1,4,4]
+    Wa = net.params.shaped("W_pc_deconv_a").double().permute(3, 2, 0, 1)          # [32,A,4,4]
+    Wcat = torch.cat([Wv, Wa], 1).contiguous()                                      # conv_transpose weight [32,1+A,4,4]
+    r_dW = torch.zeros((1 + A) * 16, 32, dtype=torch.float64, device=DEV)          # rows (o, ky, kx)
+    r_db = torch.zeros(1 + A, dtype=torch.float64, device=DEV)
+    worst = scale = 0.0
+    CH = 2048
+    for r0 in range(0, rows, CH):
+        n = min(CH, rows - r0)
+        dd = d_dec[r0:r0 + n].double().permute(0, 2, 1).reshape(n, 1 + A, 20, 20)
+        h = hp[r0:r0 + n].double().view(n, 9, 9, 32).permute(0, 3, 1, 2)          # [n,32,9,9]
+        want = F.conv2d(dd, Wcat, stride=2) * (h > 0)                              # adjoint of conv_transpose2d
+        got = d_hp[r0:r0 + n].double().view(n, 9, 9, 32).permute(0, 3, 1, 2)
+        worst = max(worst, float((got - want).abs().max()))
+        scale = max(scale, float(want.abs().max()))
+        r_dW += torch.einsum("nkp,ncp->kc", F.unfold(dd, 4, stride=2), h.reshape(n, 32, 81))
+        r_db += dd.sum((0, 2, 3))
+    assert scale > 0 and worst <= 2e-4 * scale, ("pc deconv dgrad on every other row", worst, scale)
+    r_dW = r_dW.view(1 + A, 4, 4, 32).permute(1, 2, 0, 3)                          # [ky,kx,o,c]
+    _close_grad(g["W_pc_deconv_v"].view(4, 4, 1, 32), r_dW[:, :, :1], "g[W_pc_deconv_v]")
+    _close_grad(g["W_pc_deconv_a"].view(4, 4, A, 32), r_dW[:, :, 1:], "g[W_pc_deconv_a]")
+    _close_grad(g["b_pc_deconv_a"], r_db[1:], "g[b_pc_deconv_a]")
+    # ---- pc fc wgrad: features of the EVEN rows (leading dimension doubled) x d_hp ------------------------------------
+    feat = ws.h[:rows2 * 256].view(rows, 2, 256)[:, 0]
+    ref = torch.zeros(256, 2592, dtype=torch.float64, device=DEV)
+    for r0 in range(0, rows, 8192):
+        ref += feat[r0:r0 + 8192].double().t() @ d_hp[r0:r0 + 8192].double()
+    _close_grad(g["W_pc_fc1"].view(256, 2592), ref, "g[W_pc_fc1] at %d rows" % rows)
+    _close_grad(g["b_pc_fc1"], d_hp.double().sum(0), "g[b_pc_fc1]")
+    # ---- trunk: fc1 wgrad / dgrad at 163,840 rows ------------------------------------------------------------------------
+    f2 = ws.f2[:rows2 * 2592].view(rows2, 2592)
+    d_fc = gws.d_fc[:rows2 * 256].view(rows2, 256)
+    d_f2 = gws.d_f2[:rows2 * 2592].view(rows2, 2592)
+    ref = torch.zeros(2592, 256, dtype=torch.float64, device=DEV)
+    for r0 in range(0, rows2, 8192):
+        ref += f2[r0:r0 + 8192].double().t() @ d_fc[r0:r0 + 8192].double()
+    _close_grad(g["W_base_fc1"].view(2592, 256), ref, "g[W_base_fc1] increment of the batched pass (K = %d)" % rows2)
+    _close_grad(g["b_base_fc1"], d_fc.double().sum(0), "g[b_base_fc1] increment")
+    Wd = net.params.shaped("W_base_fc1").double()
+    worst = scale = 0.0
+    for r0 in range(0, rows2, 8192):
+        want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
+        worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
+        scale = max(scale, float(want.abs().max()))
+    assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad at %d rows" % rows2, worst, scale)
+    # ---- conv encoder backward at 163,840 frames -----------------------------------------------------------------------
+    W2 = net.params.shaped("W_base_conv2").double()
+    w2_oihw = W2.permute(3, 2, 0, 1).contiguous()
+    r_dW2 = torch.zeros(256, 32, dtype=torch.float64, device=DEV)
+    r_dW1 = torch.zeros(192, 16, dtype=torch.float64, device=DEV)
+    r_db1 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    r_db2 = torch.zeros(32, dtype=torch.float64, device=DEV)
+    frames4 = ring.frames.view(-1, 84, 84, 3)
+    CH = 1024
+    for r0 in range(0, rows2, CH):
+        n = min(CH, rows2 - r0)
+        c1 = ws.c1[r0 * 6400:(r0 + n) * 6400].view(n, 20, 20, 16).double().permute(0, 3, 1, 2)
+        d2 = d_f2[r0:r0 + n].double().view(n, 9, 9, 32).permute(0, 3, 1, 2).contiguous()
+        r_db2 += d2.sum((0, 2, 3))
+        r_dW2 += torch.einsum("nkp,nop->ko", F.unfold(c1, 4, stride=2), d2.reshape(n, 32, 81))
+        d1 = F.conv_transpose2d(d2, w2_oihw, stride=2) * (c1 > 0)
+        r_db1 += d1.sum((0, 2, 3))
+        x = frames4[ws.frame_idx[r0:r0 + n].long()].double().permute(0, 3, 1, 2) * net.frame_scale
+        r_dW1 += torch.einsum("nkp,nop->ko", F.unfold(x, 8, stride=4), d1.reshape(n, 16, 400))
+    r_dW2 = r_dW2.view(16, 4, 4, 32).permute(1, 2, 0, 3).reshape(256, 32)
+    r_dW1 = r_dW1.view(3, 8, 8, 16).permute(1, 2, 0, 3).reshape(192, 16)
+    _close_grad(g["W_base_conv2"].view(256, 32), r_dW2, "g[W_base_conv2] increment at %d frames" % rows2)
+    _close_grad(g["b_base_conv2"], r_db2, "g[b_base_conv2] increment")
+    _close_grad(g["W_base_conv1"].view(192, 16), r_dW1, "g[W_base_conv1] increment")
+    _close_grad(g["b_base_conv1"], r_db1, "g[b_base_conv1] increment")

@@ -60,3 +60,33 @@ def test_launcher_returns_the_failure_and_reaps_the_survivors(tmp_path):
     r = _run(tmp_path, "2", "1")                              # rank 1 exits with code 7 before the all-reduce
     assert r.returncode != 0
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+
+
+def test_launcher_terminated_by_signal_leaves_no_rank_behind(tmp_path):
+    """SIGTERM to the launcher (an outer `timeout`) must take the ranks down with it: a rank stuck in a collective would
+    otherwise hold its GPU for ever.  The ranks here sleep; each writes its PID first."""
+    import signal
+    import time
+    rank_script = tmp_path / "sleeper.py"
+    rank_script.write_text(textwrap.dedent("""
+        import os, sys, time
+        open(os.path.join(%r, "pid.%%s" %% os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+    """) % str(tmp_path))
+    launcher = tmp_path / "launch.py"
+    launcher.write_text(LAUNCH)
+    p = subprocess.Popen([sys.executable, str(launcher), str(rank_script), "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / ("pid.%d" % r)).exists() for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid.%d" % r)).read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(60) == 128 + signal.SIGTERM
+    time.sleep(0.2)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = open("/proc/%d/stat" % pid).read().split()[2] != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, "rank process %d survived its launcher" % pid

@@ -34,8 +34,10 @@ class RecordingDraws(object):
 
 
 def _cfg(use_lstm, aux, H, T):
-    return dict(action_size=4, use_lstm=use_lstm, use_pixel_change=aux, use_value_replay=aux,
-                use_reward_prediction=aux, pixel_change_lambda=0.05, entropy_beta=0.001, local_t_max=T,
+    """aux: True / False for all three auxiliary tasks, or a (pixel_change, value_replay, reward_prediction) triple."""
+    pc, vr, rp = (aux, aux, aux) if isinstance(aux, bool) else aux
+    return dict(action_size=4, use_lstm=use_lstm, use_pixel_change=pc, use_value_replay=vr,
+                use_reward_prediction=rp, pixel_change_lambda=0.05, entropy_beta=0.001, local_t_max=T,
                 n_step_TD=T, gamma=0.99, gamma_pc=0.9, experience_history_size=H, max_time_step=10 ** 6,
                 rmsp_alpha=0.99, rmsp_epsilon=0.1, grad_norm_clip=40.0, initial_alpha_low=1e-4,
                 initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
@@ -64,6 +66,28 @@ def _build(cfg, B, seed, env_type="maze", simulator=None, frame_scale=None, env_
     return net, applier, tr, draws
 
 
+def _feed_draws(cfg, log, edraws, T, B):
+    """Replay one compute_gradients() call's recorded device draws into the oracle's per-actor draw objects.  Order per
+    call: T action uniforms, [pixel-control start], [value-replay start], [reward-prediction coin, pick]."""
+    u_act = log[0].reshape(T, B)
+    k = 1
+    for b in range(B):
+        edraws[b].action_u = [float(u_act[t, b]) for t in range(T)]
+        edraws[b].seq_starts = []
+        edraws[b].rp_coin, edraws[b].rp_u = [], []
+    for flag in ("use_pixel_change", "use_value_replay"):
+        if cfg[flag]:
+            for b in range(B):
+                edraws[b].seq_starts.append(int(log[k][b]))
+            k += 1
+    if cfg["use_reward_prediction"]:
+        for b in range(B):
+            edraws[b].rp_coin = [int(log[k][b])]
+            edraws[b].rp_u = [float(log[k + 1][b])]
+        k += 2
+    assert k == len(log), "the device made %d draw calls, the flag set explains %d" % (len(log), k)
+
+
 def _teleport(tr, orc, b, x, y):
     """Put actor b at cell (x,y) on both sides (to provoke terminals inside a rollout)."""
     ring = tr.ring
@@ -81,12 +105,23 @@ def _teleport(tr, orc, b, x, y):
     env.last_state = {'image': img}
 
 
-@pytest.mark.parametrize("use_lstm,aux", [(True, True), (False, False)])
-def test_process_matches_oracle(use_lstm, aux):
+# flag sets: full UNREAL, config 1 (FF, no aux), and the partial sets the reference's own tests build
+# (model/model_test.py:22-66: PC only = 18 variables, VR only = 12, RP only = 14 with the LSTM on; PC only is also
+# BASELINE config 4's flag set).  With exactly one of PC / VR the trainer runs the per-branch schedule
+# (_train_pc / _train_vr on the single-width workspaces), with both the batched replay pass.
+@pytest.mark.parametrize("use_lstm,aux,n_vars", [(True, True, 20), (False, False, 10),
+                                                 (True, (True, False, False), 18),
+                                                 (True, (False, True, False), 12),
+                                                 (True, (False, False, True), 14),
+                                                 (True, (True, False, True), 20),
+                                                 (False, (True, True, False), 16)])
+def test_process_matches_oracle(use_lstm, aux, n_vars):
     B, H, T = 3, 40, 20
     cfg = _cfg(use_lstm, aux, H, T)
     cfg["initial_learning_rate"] = 7.0711e-4
     net, applier, tr, draws = _build(cfg, B, seed=3)
+    assert len(net.get_vars()) == n_vars                      # model/model_test.py:14-58
+    assert tr.batch_aux == (cfg["use_pixel_change"] and cfg["use_value_replay"])
     named = net.export_named()
     params = {k: torch.tensor(v, dtype=torch.float64) for k, v in named.items()}
     edraws = [ExplicitDraws() for _ in range(B)]
@@ -128,17 +163,7 @@ def test_process_matches_oracle(use_lstm, aux):
         losses_dev = tr._publish_losses()
 
         # replay the draws into the oracle
-        u_act = draws.log[0].reshape(T, B)
-        k = 1
-        for b in range(B):
-            edraws[b].action_u = [float(u_act[t, b]) for t in range(T)]
-            edraws[b].seq_starts = []
-            edraws[b].rp_coin, edraws[b].rp_u = [], []
-        if aux:
-            for b in range(B):
-                edraws[b].seq_starts = [int(draws.log[1][b]), int(draws.log[2][b])]
-                edraws[b].rp_coin = [int(draws.log[3][b])]
-                edraws[b].rp_u = [float(draws.log[4][b])]
+        _feed_draws(cfg, draws.log, edraws, T, B)
         steps_o, infos, losses_o, mean_g, norm_o = orc.process_batched(global_t)
 
         # ---- exact: step counts, actions, rewards, terminals ------------------------------------
@@ -164,6 +189,8 @@ def test_process_matches_oracle(use_lstm, aux):
             if key in losses_o[0]:
                 want = np.mean([l[key] for l in losses_o])
                 assert abs(losses_dev[key] - want) <= 2e-4 + 2e-4 * abs(want), (it, key, losses_dev[key], want)
+            else:
+                assert losses_dev[key] == 0.0, (key, losses_dev[key])          # a task that is off contributes nothing
         want_ent = np.mean([l["entropy"].sum() for l in losses_o])
         assert abs(losses_dev["entropy"] - want_ent) <= 2e-4 + 2e-4 * abs(want_ent)
 
@@ -330,12 +357,7 @@ def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_fr
         ops.rollout_stats(B, tr.n_steps, tr.ring.score_valid, tr.ring.score_out, tr.stats)
         steps_dev, episodes_dev, score_dev = tr.read_stats()
         losses_dev = tr._publish_losses()
-        u_act = draws.log[0].reshape(T, B)
-        for b in range(B):
-            edraws[b].action_u = [float(u_act[t, b]) for t in range(T)]
-            edraws[b].seq_starts = [int(draws.log[1][b]), int(draws.log[2][b])]
-            edraws[b].rp_coin = [int(draws.log[3][b])]
-            edraws[b].rp_u = [float(draws.log[4][b])]
+        _feed_draws(cfg, draws.log, edraws, T, B)
         steps_o, infos, losses_o, mean_g, norm_o = orc.process_batched(global_t)
         n_dev = tr.n_steps.cpu().numpy()
         acts = tr.actions.cpu().numpy().reshape(T, B)
@@ -348,6 +370,9 @@ def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_fr
         sc = [i["score"] for i in infos if i["score"] is not None]
         assert episodes_dev == len(sc) and (not sc or abs(score_dev - sum(sc)) < 1e-5)
         for key in ("policy_loss", "value_loss", "pc_loss", "vr_loss", "rp_loss", "total_loss"):
+            if key not in losses_o[0]:
+                assert losses_dev[key] == 0.0
+                continue
             want = np.mean([l[key] for l in losses_o])
             assert abs(losses_dev[key] - want) <= 3e-4 + 3e-4 * abs(want), (it, key, losses_dev[key], want)
         for (name, _), gref in zip(orc.params.items(), mean_g):
@@ -358,8 +383,10 @@ def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_fr
         global_t += steps_dev
 
 
-@pytest.mark.parametrize("B", [3, 4])       # 4: two half-batches alternate between host and device (overlap_host)
-def test_hostfed_lab_contract_matches_oracle(B):
+# B = 4: two half-batches alternate between host and device (overlap_host).  aux (False, ...) = BASELINE config 4's own
+# flag set, "A3C-LSTM + pixel-control": no value replay, no reward prediction -> the per-branch _train_pc schedule
+@pytest.mark.parametrize("B,aux", [(3, True), (4, True), (3, (True, False, False)), (4, (True, False, False))])
+def test_hostfed_lab_contract_matches_oracle(B, aux):
     """SURVEY 8f-1 / BASELINE config 4: host simulators (synthetic stand-in for DeepMind Lab: uint8 frames, A = 6,
     sparse rewards incl. values > 1, fixed-length episodes) -> pinned staging -> HBM ring -> the same batched
     learner, against the oracle running the Lab wrapper contract (lab_environment.py:78-119) with the upstream
@@ -367,7 +394,7 @@ def test_hostfed_lab_contract_matches_oracle(B):
     from oracle.hostfed import OracleLabEnv
     from unreal_amd.environment.synthetic_sim import SyntheticBatchSimulator, SyntheticActorSim
     H, T = 40, 20
-    cfg = _cfg(True, True, H, T)
+    cfg = _cfg(True, aux, H, T)
     cfg.update(action_size=6, lab_ver=True, initial_learning_rate=7.0711e-4)
     kw = dict(episode_len=23, reward_p=0.2, big_reward_p=0.06)
     sim = SyntheticBatchSimulator(B, seed=4, **kw)

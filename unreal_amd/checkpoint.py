@@ -12,6 +12,7 @@ False)` reproduces the reference's behaviour.  Replay, LSTM state and RNG are no
 import glob
 import os
 import re
+import warnings
 
 import numpy as np
 import torch
@@ -26,13 +27,21 @@ def checkpoint_name(best_score, global_t, name=""):
     return "%s-%s-%d.pt" % (base, str(abs(float(best_score)))[2:8], int(global_t))
 
 
-def list_checkpoints(checkpoint_dir):
-    """[(global_t, path)] sorted by global_t."""
+def list_checkpoints(checkpoint_dir, name=""):
+    """[(global_t, path)] of the checkpoints called `name` (default "checkpoint"), sorted by global_t.  Files that do not
+    start with that name (best.pt, an exported model, another run's prefix) are not ours: they are left alone with a
+    warning, like the reference's Saver ignores unrelated files (main.py:356-427).  A file that DOES carry the prefix but
+    whose tail is not <score digits>-<global_t>.pt raises: it would be skipped by restore and by pruning alike."""
+    base = name if name else "checkpoint"
     out = []
-    for p in glob.glob(os.path.join(checkpoint_dir, "*.pt")):
-        m = _NAME.match(os.path.basename(p))
-        if m is None:            # never skip silently: a mis-named file would be ignored by restore AND by pruning
-            raise ValueError("%s does not follow <name>-<score digits>-<global_t>.pt" % p)
+    for p in sorted(glob.glob(os.path.join(checkpoint_dir, "*.pt"))):
+        fn = os.path.basename(p)
+        if not fn.startswith(base + "-"):
+            warnings.warn("%s: not a '%s-*' checkpoint, ignored" % (p, base))
+            continue
+        m = _NAME.match(fn)
+        if m is None or m.group("prefix") != base:
+            raise ValueError("%s does not follow %s-<score digits>-<global_t>.pt" % (p, base))
         out.append((int(m.group("t")), p))
     return sorted(out)
 
@@ -57,7 +66,7 @@ def save(checkpoint_dir, net, applier, global_t, wall_t, best_score=0.0, name=""
     }
     path = os.path.join(checkpoint_dir, checkpoint_name(best_score, global_t, name))
     torch.save(payload, path)
-    ck = list_checkpoints(checkpoint_dir)
+    ck = list_checkpoints(checkpoint_dir, name)
     for t, p in ck[:-MAX_TO_KEEP]:
         os.remove(p)
         w = os.path.join(checkpoint_dir, "wall_t." + str(t))
@@ -66,9 +75,9 @@ def save(checkpoint_dir, net, applier, global_t, wall_t, best_score=0.0, name=""
     return path
 
 
-def restore(checkpoint_dir, net, applier=None, restore_slots=True):
+def restore(checkpoint_dir, net, applier=None, restore_slots=True, name=""):
     """-> (global_t, wall_t, best_score) of the newest checkpoint, or None if there is none."""
-    ck = list_checkpoints(checkpoint_dir)
+    ck = list_checkpoints(checkpoint_dir, name)
     if not ck:
         return None
     global_t, path = ck[-1]

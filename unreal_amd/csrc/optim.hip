@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ var, f
 }
 
 // dst[i] = src[i] for 4-byte words: the state hand-overs of the hot path (LSTM state, index lists) are launched as an
-// ordinary kernel of this library rather than as hipMemcpyDtoDAsync (whose runtime blit kernel rocprofv3 --pmc
-// cannot instrument: the profiler segfaults inside at::native::copy_device_to_device, profiles/r02_pmc_fault.log).
+// ordinary kernel of this library rather than as hipMemcpyDtoDAsync: every dispatch of process() is then a kernel of
+// this library that shows up by name in a kernel trace (the runtime's blit kernel does not).  NOTE: round 2 blamed a
+// rocprofv3 --pmc crash on that blit kernel; the crash came back with no D2D copy left and went away once the replay
+// fill stopped queueing ~24 k dispatches without a host sync -- same trigger both times as far as the evidence goes
+// (profiles/r02_pmc_fault.log).  Trainer._fill_experience now bounds that queue itself.
 __global__ void copy_words_kernel(long n, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int vec) {
   const long stride = (long)gridDim.x * blockDim.x;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -116,11 +116,30 @@ class GradWS(object):
             self.d_gates = f(rows * 1024)
             self.dh_rec = f(B * 256)
             self.dc = f(B * 256)
+        self.rows, self.lstm, self.device = rows, lstm, device
+        self.hp = self.d_hp = self.d_dec = self.pc_R = None
         if pc:
-            self.hp = f(pc_rows * ops.F2_DIM)
-            self.d_hp = f(pc_rows * ops.F2_DIM) if pc_rows != rows else None      # else callers use d_f2
-            self.d_dec = f(pc_rows * ops.PC_CELLS * (1 + A))
-            self.pc_R = f(pc_rows * ops.PC_CELLS)
+            self.ensure_pc(pc_rows, A, own_d_hp=pc_rows != rows)
+
+    def ensure_pc(self, pc_rows, A, own_d_hp=False):
+        """Pixel-control temporaries for `pc_rows` rows (allocated once; callers without their own d_hp use d_f2)."""
+        if self.hp is not None and self.hp.numel() >= pc_rows * ops.F2_DIM:
+            return
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
+        self.hp = f(pc_rows * ops.F2_DIM)
+        self.d_hp = f(pc_rows * ops.F2_DIM) if own_d_hp else None
+        self.d_dec = f(pc_rows * ops.PC_CELLS * (1 + A))
+        self.pc_R = f(pc_rows * ops.PC_CELLS)
+
+    def ensure_rows(self, rows, B, device):
+        """Grow the row-sized temporaries (a per-branch replay pass on a trainer that was sized for the batched one)."""
+        if rows <= self.rows:
+            return
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
+        self.rows = rows
+        self.d_feat, self.d_fc, self.d_f2 = f(rows * 256), f(rows * 256), f(rows * ops.F2_DIM)
+        if self.lstm:
+            self.d_gates = f(rows * 1024)
 
 
 def _splitk(M, N, K):

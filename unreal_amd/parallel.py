@@ -123,44 +123,80 @@ def free_port():
     return port
 
 
+class _Terminated(Exception):
+    pass
+
+
 def launch_ranks(script, argv, world, extra_env=None, poll_s=0.5, grace_s=20.0):
     """Start `world` children `python script argv...`, one per rank, from a parent that has not touched the GPU.
     Rank 0's stdout is relayed to this process's stdout, the other ranks' stdout goes to stderr (so the caller
     still sees exactly one JSON line).  If a rank dies, the survivors get `grace_s` seconds, then are terminated by
-    PID (they would otherwise wait in a collective forever).  Returns the worst exit code."""
-    port = free_port()
+    PID (they would otherwise wait in a collective forever).  The same happens when THIS process is interrupted
+    (KeyboardInterrupt) or receives SIGTERM / SIGHUP (an outer `timeout`): no rank outlives its launcher holding a
+    GPU.  Returns the worst exit code (130 / 143 after an interrupt / a termination signal)."""
+    import signal
     procs = []
-    for r in range(world):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
-        env.setdefault("OMP_NUM_THREADS", "4")
-        if extra_env:
-            env.update(extra_env)
-        out = None if r == 0 else sys.stderr
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
-    first_fail = None
-    while True:
-        codes = [p.poll() for p in procs]
-        if all(c is not None for c in codes):
-            break
-        if first_fail is None and any(c not in (None, 0) for c in codes):
-            first_fail = time.time()
-        if first_fail is not None and time.time() - first_fail > grace_s:
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(10)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(poll_s)
-    codes = [p.wait() for p in procs]
+    interrupted = 0
+
+    def _on_signal(signum, frame):
+        raise _Terminated(signum)
+
+    old = {}
+    for sig in (signal.SIGTERM, signal.SIGHUP):
+        try:
+            old[sig] = signal.signal(sig, _on_signal)
+        except ValueError:               # not the main thread: the caller's own handlers stay
+            pass
+
+    def _reap():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        for p in procs:
+            p.wait()
+
+    try:
+        # free_port() closes its probe socket before rank 0 binds the rendezvous port (a check-then-use window of a few
+        # ms on 127.0.0.1); a collision makes rank 0 exit with "address already in use" and the launcher returns its code
+        port = free_port()
+        for r in range(world):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(world))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
+            env.setdefault("OMP_NUM_THREADS", "4")
+            if extra_env:
+                env.update(extra_env)
+            out = None if r == 0 else sys.stderr
+            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+        first_fail = None
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if first_fail is None and any(c not in (None, 0) for c in codes):
+                first_fail = time.time()
+            if first_fail is not None and time.time() - first_fail > grace_s:
+                break                                  # the finally block terminates the survivors
+            time.sleep(poll_s)
+    except KeyboardInterrupt:
+        interrupted = 130
+    except _Terminated as e:
+        interrupted = 128 + int(e.args[0])
+    finally:
+        _reap()
+        for sig, h in old.items():
+            signal.signal(sig, h)
+    if interrupted:
+        return interrupted
     worst = 0
-    for c in codes:
+    for c in [p.returncode for p in procs]:
         if c != 0:
             worst = c if c > 0 else 128 - c
             break

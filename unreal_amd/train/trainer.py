@@ -163,13 +163,17 @@ class Trainer(object):
         xld = self.local_network.xld
         self.base_ws = PathWS(T * B, B, dev, save_c1=True, lstm=lstm, xld=xld)
         self.boot_ws = PathWS(B, B, dev, save_c1=False, lstm=lstm, xld=xld)
-        self.aux_ws = PathWS(Ta * B, B, dev, save_c1=True, lstm=lstm, xld=xld) if aux else None
         self.rp_ws = PathWS(3 * B, B, dev, save_c1=True, lstm=False, xld=xld) if self.use_reward_prediction else None
-        rows = max(T, Ta if aux else 0, 3 if self.use_reward_prediction else 0) * B
-        self.gws = GradWS(rows, B, dev, lstm=lstm, pc=self.use_pixel_change, A=A)
         # pixel control and value replay as ONE batch of 2B replayed sequences (actor 2b = pc sample of b, 2b + 1 = vr
-        # sample): see _train_aux_batched
+        # sample): see _train_aux_batched.  Decided HERE, once (the class default is read at prepare() time only).
         self.batch_aux = bool(self.batch_aux_default and self.use_pixel_change and self.use_value_replay)
+        # per-branch workspaces (_train_pc / _train_vr: one of the two tasks on, or batch_aux off) are allocated on first
+        # use: with the batched pass they would be ~5 GB of dead HBM per rank at 4096 actors
+        self._aux_ws = None
+        self._aux_ws_args = (Ta * B, B, dev, lstm, xld) if aux else None
+        per_branch = aux and not self.batch_aux
+        rows = max(T, Ta if per_branch else 0, 3 if self.use_reward_prediction else 0) * B
+        self.gws = GradWS(rows, B, dev, lstm=lstm, pc=self.use_pixel_change and per_branch, A=A)
         if self.batch_aux:
             self.aux2_ws = PathWS(Ta * 2 * B, 2 * B, dev, save_c1=True, lstm=lstm, xld=xld)
             self.boot2_ws = PathWS(2 * B, 2 * B, dev, save_c1=False, lstm=lstm, xld=xld)
@@ -219,6 +223,15 @@ class Trainer(object):
             self._group_views.append((env, self.full_lstm_c[b0 * 256:b1 * 256], self.full_lstm_h[b0 * 256:b1 * 256], b0))
         self._select_group(0)
 
+    @property
+    def aux_ws(self):
+        """Workspace of the one-branch-at-a-time replay schedule (lazy: see prepare())."""
+        if self._aux_ws is None and self._aux_ws_args is not None:
+            rows, B, dev, lstm, xld = self._aux_ws_args
+            self._aux_ws = PathWS(rows, B, dev, save_c1=True, lstm=lstm, xld=xld)
+            self.gws.ensure_rows(rows, B, dev)
+        return self._aux_ws
+
     def _select_group(self, g):
         """Point the pipeline at the actors [g*Bg, (g+1)*Bg): environment / ring views, carried LSTM state, draws."""
         env, c, h, b0 = self._group_views[g]
@@ -257,6 +270,8 @@ class Trainer(object):
         feat, ld = net.features(ws, t * B)
         net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
 
+    FILL_SYNC_EVERY = 64
+
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
         # weights are frozen while the replay fills: split them on the first call (or after an announced load)
@@ -266,6 +281,11 @@ class Trainer(object):
             self._fill_group()
         self._select_group(0)
         self._fill_calls += 1
+        # bound the queue of un-synchronised dispatches: a fill call is ~12 launches and returns at once, so a caller's
+        # `while not full: process()` loop would put ~24 k dispatches in flight within a second -- rocprofv3's counter
+        # thread does not survive that (profiles/r02_pmc_fault.log).  The fill is untimed; a sync every 64 calls is free.
+        if self._fill_calls % self.FILL_SYNC_EVERY == 0:
+            torch.cuda.current_stream().synchronize()
         if self._fill_calls >= self.experience_history_size:
             full = self.experience.is_full()
             if self.world_size > 1:            # every rank leaves the fill phase in the SAME call (the learn phase
@@ -425,6 +445,8 @@ class Trainer(object):
         B, Ta, A, net = self.Bg, self.local_t_max, self.action_size, self.local_network
         p, g, gws = net.p, net.g, self.gws
         rows = Ta * B
+        ws = self.aux_ws                              # (allocates the per-branch workspace on first use)
+        gws.ensure_pc(rows, A)
         feat, ld = self._sample_sequence()
         net.pc_head_forward(B, feat, ld, self.boot_hp)
         ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
@@ -451,6 +473,7 @@ class Trainer(object):
         B, Ta, net = self.Bg, self.local_t_max, self.local_network
         p, g, gws = net.p, net.g, self.gws
         rows = Ta * B
+        ws = self.aux_ws                              # (allocates the per-branch workspace on first use)
         feat, ld = self._sample_sequence()
         net.value_forward(B, feat, ld, self.aux_boot_v)
         ops.vr_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.aux_boot_v, self.gamma, self.aux_R)
@@ -461,7 +484,7 @@ class Trainer(object):
                              g["W_base_fc_v"], g["b_base_fc_v"])
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
 
-    batch_aux_default = True       # class default (tools/exp/ab_process.py rebuilds the trainer to compare)
+    batch_aux_default = True       # class default, read by prepare() only (A/B tools build a second Trainer with it off)
 
     def _train_aux_batched(self):
         """[Pixel change] + [Value replay] (trainer.py:339-412) as ONE trunk pass over 2B replayed sequences: sequence
@@ -546,7 +569,7 @@ class Trainer(object):
         net.grads.flat.zero_()
         self.losses.zero_()
         self._train_base()
-        if self.batch_aux and self.batch_aux_default:        # (the class attribute can be flipped at run time for A/B timing)
+        if self.batch_aux:
             self._train_aux_batched()
         else:
             if self.use_pixel_change:
