@@ -71,10 +71,26 @@ def build_trainer(args, rank, world, device):
     return flags, net, tr
 
 
-def cpu_baseline(seconds, threads, history):
+def host_cpus():
+    """CPUs this process may use: the affinity mask, cut to the cgroup's CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(legs, history, extra_history=100):
     """The oracle's restatement of the reference's threaded loop (main.py:72-162 + trainer.py:438-636):
     `threads` Python threads, each one actor with batch-1 forwards, numpy maze, deque-like replay, its own
-    gradient and a hogwild RMSProp step on shared parameters; PyTorch-CPU fp32, one intra-op thread."""
+    gradient and a hogwild RMSProp step on shared parameters; PyTorch-CPU fp32, one intra-op thread.
+    `legs` = [(threads, seconds)]: timed one after the other on ONE trainer (parallel_size = 8, also 1 and
+    nproc).  The first 8 actors carry the workload's replay history; actors beyond them (the nproc leg) a short one
+    (`extra_history`) so the untimed fill of hundreds of actors stays bounded -- replay length does not enter the cost
+    of a step.  -> [(threads, env-steps/s, env-steps, seconds)]"""
     from oracle.trainer import OracleTrainer
     torch.set_num_threads(1)
     cfg = dict(action_size=4, use_lstm=True, use_pixel_change=True, use_value_replay=True,
@@ -82,24 +98,42 @@ def cpu_baseline(seconds, threads, history):
                n_step_TD=20, gamma=0.99, gamma_pc=0.9, experience_history_size=history,
                max_time_step=int(13.2e6), rmsp_alpha=0.99, rmsp_epsilon=0.1, grad_norm_clip=40.0,
                initial_alpha_low=1e-4, initial_alpha_high=5e-3, initial_alpha_log_rate=0.5)
-    tr = OracleTrainer(cfg, n_actors=threads, seed=1)
-    tr.fill()
-    steps = [0] * threads
-    stop = time.time() + seconds
-    t0 = time.time()
+    n_max = max(t for t, _ in legs)
+    tr = OracleTrainer(cfg, n_actors=min(8, n_max), seed=1)
+    if n_max > 8:                                      # the extra actors of the nproc leg: same network, short replay
+        from oracle.trainer import OracleActor
+        cfg2 = dict(cfg, experience_history_size=extra_history)
+        tr.actors += [OracleActor(cfg2, tr.actors[0].draws, tr.dtype) for _ in range(n_max - 8)]
 
-    def work(i):
-        while time.time() < stop:
-            d, _, _ = tr.process_async(i, sum(steps))
-            steps[i] += d
+    def fill(i):                                       # replay fill, untimed (weights frozen: actors are independent)
+        a = tr.actors[i]
+        while not a.exp.is_full():
+            a.fill_step(tr.params)
 
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    ths = [threading.Thread(target=fill, args=(i,)) for i in range(n_max)]
     for t in ths:
         t.start()
     for t in ths:
         t.join()
-    el = time.time() - t0
-    return sum(steps) / el, sum(steps), el
+    out = []
+    for threads, seconds in legs:
+        steps = [0] * threads
+        stop = time.time() + seconds
+        t0 = time.time()
+
+        def work(i):
+            while time.time() < stop:
+                d, _, _ = tr.process_async(i, sum(steps))
+                steps[i] += d
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        el = time.time() - t0
+        out.append((threads, sum(steps) / el, sum(steps), el))
+    return out
 
 
 def main():
@@ -111,7 +145,8 @@ def main():
     ap.add_argument("--history", type=int, default=2000, help="experience_history_size per actor")
     ap.add_argument("--groups", type=int, default=1, help="sequential updates per process() call (actors are dealt into "
                     "this many groups; 1 = one update from all actors, the headline configuration)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="total timed CPU-baseline budget: half of it for the "
+                    "parallel_size leg, a quarter each for the 1-thread and the nproc-thread legs")
     ap.add_argument("--cpu-threads", type=int, default=8, help="parallel_size of the reference (options.py:37)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-kernel", default="unreal_encoder_bwd")
@@ -119,6 +154,11 @@ def main():
     args = ap.parse_args()
 
     from unreal_amd import parallel
+    if args.gpus > 1 and "UNREAL_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
+        # (device_count() does not initialise the GPU: the launcher below stays a process that never touched it)
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s).  One rank per GPU over RCCL needs %d devices; "
+                         "to rehearse several ranks on one device set UNREAL_FORCE_DEVICE=0 (gloo, not a measurement)."
+                         % (args.gpus, torch.cuda.device_count(), args.gpus))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher only: nothing in this process has touched (or will touch) the GPU
         sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
@@ -161,6 +201,7 @@ def main():
     tr.read_stats()
     mark("warm-up done")
     ops.kernel_timer_start(args.timed_kernel)
+    tr.time_grad_sync = world > 1                     # HIP events around the gradient exchange of every timed update
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -171,12 +212,16 @@ def main():
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     kt = ops.kernel_timer_stop()
+    comm_ms = tr.grad_sync_ms()                       # [ms per update] of this rank (empty at world == 1)
     steps_local, episodes, score_sum = tr.read_stats()
     elapsed = parallel.max_over_ranks(elapsed, device)
     tot_steps, tot_eps, tot_score = parallel.sum_over_ranks([steps_local, episodes, score_sum], device)
     losses = tr._publish_losses()
+    per_rank_steps = parallel.gather_over_ranks(steps_local, device)
+    per_rank_comm = parallel.gather_over_ranks(sum(comm_ms) / len(comm_ms) if comm_ms else 0.0, device)
 
     backend = parallel.backend_name()
+    ranks_formed = parallel.world_size()
     if rank != 0:
         parallel.shutdown()
         return
@@ -188,10 +233,20 @@ def main():
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r02_pmc_bench.json,
     # corrected as MI355X_MICROARCH.md prescribes: FETCH doubled), mean over the launches of its timed calls.
-    traffic = None
+    # The PMC file records the launch it measured (frames per launch, actors, groups); the figure is scaled to THIS run's
+    # frames per launch when the schedule is the profiled one (same groups: same mix of launches) and null otherwise.
+    traffic, traffic_note = None, "no PMC summary for this kernel"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
-        traffic = pmc[args.timed_kernel.replace("unreal_", "") + "_kernel"]["hbm_bytes_per_launch"]
+        doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        k = doc["kernels"][args.timed_kernel.replace("unreal_", "") + "_kernel"]
+        prof = doc.get("profiled_run", {"actors": 4096, "groups": 1, "frames_per_launch": 86016.0})
+        if prof.get("groups", 1) == args.groups and frames_per_launch > 0:
+            traffic = k["hbm_bytes_per_launch"] * frames_per_launch / float(prof["frames_per_launch"])
+            traffic_note = "HBM bytes per launch: in-situ rocprofv3 --pmc passes of bench.py (profiles/%s, measured at " \
+                           "%d frames per launch, scaled by frames to this run's %d)" % (
+                               PMC_FILE, prof["frames_per_launch"], frames_per_launch)
+        else:
+            traffic_note = "profiles/%s was measured with groups=%s: not comparable with this run" % (PMC_FILE, prof.get("groups"))
     except Exception:
         pass
     peak = ENC_BWD_PEAK_TFLOPS if "bwd" in args.timed_kernel else FP32_MFMA_PEAK_TFLOPS
@@ -206,14 +261,20 @@ def main():
                    "updates_per_call": args.groups,
                    "env_steps_per_call": tot_steps / args.steps, "parallelism": "actors sharded x%d, flat-gradient "
                    "all-reduce (%s)" % (world, backend) if world > 1 else "single GPU", "replay_fill_s": t_fill,
+                   # what the exchange actually ran on (the driver, not the builder, runs N > 1 on real GPUs)
+                   "backend": backend, "rccl_ranks": ranks_formed if backend == "nccl" else 0, "ranks": ranks_formed,
+                   "devices_visible": torch.cuda.device_count(),
+                   "env_steps_per_rank": [int(x) for x in per_rank_steps],
+                   "grad_message_bytes": int(net.grads.flat.numel()) * 4,
+                   "comm_ms_per_update": (sum(per_rank_comm) / len(per_rank_comm)) if world > 1 else 0.0,
+                   "comm_ms_per_update_per_rank": [round(x, 4) for x in per_rank_comm] if world > 1 else [],
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
         "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "peak_note": "fp32-equivalent: dense bf16 MFMA peak (2500 TF) over the kernel's bf16 passes (conv2 "
                                   "wgrad + dgrad x6, conv1 wgrad x3); against the fp32 MFMA peak (157.3) the fraction is "
                                   "%.3f" % (achieved / FP32_MFMA_PEAK_TFLOPS),
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (in-situ PMC passes of bench.py, "
-                                                         "profiles/%s)" % PMC_FILE,
+                     "traffic": traffic, "traffic_unit": traffic_note,
                      "algorithmic_bytes_per_launch": 57136.0 * frames_per_launch,
                      "launches": kt["launches"], "avg_launch_ms": avg_ms,
                      "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),
@@ -222,12 +283,26 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         hist_cpu = args.history          # the workload's own replay history (its fill is untimed, like the GPU's)
-        v, s, el = cpu_baseline(args.cpu_seconds, args.cpu_threads, hist_cpu)
-        out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": args.cpu_threads, "kind": "port",
-                               "host_cores": os.cpu_count(),
-                               "sample": "%d env-steps in %.1f s: %d Python threads x full-UNREAL process() "
-                                         "(oracle/trainer.py, PyTorch-CPU fp32, 1 intra-op thread each), replay "
-                                         "history %d/thread (fill untimed)" % (s, el, args.cpu_threads, hist_cpu)}
+        nproc = host_cpus()
+        legs = [(1, args.cpu_seconds / 4.0), (args.cpu_threads, args.cpu_seconds / 2.0)]
+        if nproc not in (1, args.cpu_threads):
+            legs.append((nproc, args.cpu_seconds / 4.0))
+        res = cpu_baseline(legs, hist_cpu)
+        main_leg = [r for r in res if r[0] == args.cpu_threads][0]
+        desc = lambda r: "%d env-steps in %.1f s on %d Python thread%s" % (r[2], r[3], r[0], "" if r[0] == 1 else "s")
+        out["cpu_baseline"] = {"value": main_leg[1], "unit": "env-steps/s", "cores": args.cpu_threads, "kind": "port",
+                               "host_cores": nproc, "host_cores_online": os.cpu_count(),
+                               "by_threads": [{"threads": r[0], "value": r[1], "env_steps": r[2], "seconds": r[3]} for r in res],
+                               "sample": "%s (value; %s): each thread = one actor running full-UNREAL process() of "
+                                         "oracle/trainer.py on PyTorch-CPU fp32, 1 intra-op thread each, shared hogwild "
+                                         "RMSProp; replay history %d per thread for the first 8 actors, 100 for the extra "
+                                         "actors of the nproc leg; fills untimed" % (
+                                             desc(main_leg), "; ".join(desc(r) for r in res if r is not main_leg), hist_cpu)}
+    side = os.environ.get("UNREAL_BENCH_SIDECAR")      # tools/pmc_bench.sh: what the counter passes measured
+    if side:
+        json.dump({"actors": args.actors, "groups": args.groups, "steps": args.steps, "warmup": args.warmup,
+                   "history": args.history, "timed_kernel": args.timed_kernel, "frames_per_launch": frames_per_launch,
+                   "launches_timed": kt["launches"], "ms_per_step": elapsed / args.steps * 1e3}, open(side, "w"))
     print(json.dumps(out), flush=True)
     parallel.shutdown()
 

@@ -132,3 +132,21 @@ def test_bench_self_launches_its_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["global_actors"] == 128 and "gloo" in out["config"]["parallelism"]
     assert "cpu_baseline" not in out                                    # rank 0 at N = 1 only
+    # the N > 1 line is self-evidencing: what the exchange ran on, how many ranks formed, what each rank did, what the
+    # exchange cost per update (HIP events around grad_sync inside the timed region) and how big the message is
+    c = out["config"]
+    assert c["backend"] == "gloo" and c["ranks"] == 2 and c["rccl_ranks"] == 0          # rehearsal on one device
+    assert len(c["env_steps_per_rank"]) == 2 and sum(c["env_steps_per_rank"]) == round(c["env_steps_per_call"] * 2)
+    assert all(0 < x <= 64 * 20 * 2 for x in c["env_steps_per_rank"])
+    assert c["grad_message_bytes"] >= 1898877 * 4 and c["comm_ms_per_update"] > 0
+    assert len(c["comm_ms_per_update_per_rank"]) == 2
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` on a node with fewer GPUs (and no UNREAL_FORCE_DEVICE rehearsal) must fail fast with a clear message
+    instead of hanging in the rendezvous or stacking ranks on one device."""
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("UNREAL_FORCE_DEVICE", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"UNREAL_FORCE_DEVICE" in r.stderr and not r.stdout.strip()

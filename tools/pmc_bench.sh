@@ -7,6 +7,7 @@ OUT=$(realpath -m "$1"); shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export UNREAL_BENCH_SIDECAR="$OUT/bench_run.json"      # bench.py records what it ran (actors, groups, frames per launch)
 run() {   # name, counters...
   local name=$1; shift
   timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- \
@@ -20,6 +21,5 @@ run fetch FETCH_SIZE && run write WRITE_SIZE && run mfma SQ_VALU_MFMA_BUSY_CYCLE
 run waves SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT
 rc=$?
 # raw per-dispatch CSVs are tens of MB per pass: keep the per-kernel summary only
-STEPS=2; for ((i=0;i<${#ARGS[@]};i++)); do [ "${ARGS[$i]}" = "--steps" ] && STEPS=${ARGS[$((i+1))]}; done
-python3 "$ROOT/tools/pmc_insitu.py" "$OUT" --steps "$STEPS" > "$OUT/pmc_bench.json" && rm -rf "$OUT"/fetch "$OUT"/write "$OUT"/mfma "$OUT"/waves
+python3 "$ROOT/tools/pmc_insitu.py" "$OUT" > "$OUT/pmc_bench.json" && rm -rf "$OUT"/fetch "$OUT"/write "$OUT"/mfma "$OUT"/waves
 exit $rc

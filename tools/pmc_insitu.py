@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes tools/pmc_bench.sh took of bench.py itself: per kernel, over the dispatches of
-the TIMED region (the last `steps` process() calls), mean counter value per launch.
+the TIMED region, mean counter value per launch.
+  The timed region is found in the trace itself, not from constants: every learner update ends with exactly one
+  `rmsprop_kernel` launch, bench.py makes `warmup` untimed and `steps` timed process() calls of `groups` updates each
+  (bench_run.json, written by bench.py under UNREAL_BENCH_SIDECAR), so the timed dispatches are those after update number
+  warmup*groups and up to the last update -- whatever the schedule (batch_aux, groups, fuse_bptt) launches inside.
   FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md HBM), WRITE_SIZE as is, both
   in KB -> hbm_bytes_per_launch.
-usage: tools/pmc_insitu.py <outdir of pmc_bench.sh> --steps K [--calls-per-step kernel=count ...] > profiles/rNN_pmc_bench.json"""
+usage: tools/pmc_insitu.py <outdir of pmc_bench.sh> > profiles/rNN_pmc_bench.json"""
 import argparse
 import collections
 import csv
@@ -13,20 +17,9 @@ import os
 
 ap = argparse.ArgumentParser()
 ap.add_argument("outdir")
-ap.add_argument("--steps", type=int, required=True)
 args = ap.parse_args()
-
-PER_STEP = {"encoder_bwd_kernel": 3, "encoder_fwd_kernel": 24, "pc_deconv_fwd_kernel": 2, "pc_deconv_bwd_kernel": 1,
-            "maze_step_kernel": 20, "gemm_split_tn_kernel": 8, "rmsprop_kernel": 1,
-            # the NT kernel's instantiations are different kernels: big forward / dgrad products, the whole-kernel LSTM
-            # step (4096-row rollout / bootstrap steps; 8192-row steps of the batched replay pass), the 4096-row fc, the
-            # fused BPTT steps (4096 rows: base; 8192 rows: replay pass)
-            "gemm_split_nt_kernel<128, 128, true, false, 0, 1, false>": 8,
-            "gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>": 22,
-            "gemm_split_nt_kernel<128, 128, true, false, 1, 1, true>": 20,
-            "gemm_split_nt_kernel<64, 64, true, true, 0, 4, false>": 22,
-            "gemm_split_nt_kernel<64, 64, true, true, 2, 4, false>": 19,
-            "gemm_split_nt_kernel<64, 64, true, true, 2, 2, false>": 19}
+run = json.load(open(os.path.join(args.outdir, "bench_run.json")))
+DELIM = "rmsprop_kernel"
 
 
 def short(name):
@@ -34,21 +27,39 @@ def short(name):
     return n if n.startswith("gemm_split_nt_kernel") else n.split("<")[0]
 
 
-out = {"_how": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps %d (tools/pmc_bench.sh; one "
-               "pass per counter group); mean per launch over the launches of the timed process() calls; FETCH_SIZE "
-               "doubled per MI355X_MICROARCH.md, WRITE_SIZE as is (KB)" % args.steps, "kernels": {}}
+out = {"_how": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps %d --warmup %d "
+               "(tools/pmc_bench.sh; one pass per counter group); mean per launch over the launches of the timed "
+               "process() calls (found by their rmsprop_kernel delimiters); FETCH_SIZE doubled per MI355X_MICROARCH.md, "
+               "WRITE_SIZE as is (KB)" % (run["steps"], run["warmup"]),
+       "profiled_run": run, "kernels": {}}
 for p in sorted(glob.glob(os.path.join(args.outdir, "*", "*", "*counter_collection.csv"))):
+    rows = list(csv.DictReader(open(p)))
+    key = "Dispatch_Id" if rows and "Dispatch_Id" in rows[0] else None
+    if key:
+        rows.sort(key=lambda r: int(r[key]))
+    # dispatch ids of the update delimiters (one row per counter per dispatch: de-duplicate)
+    seen, delims = set(), []
+    for i, r in enumerate(rows):
+        if short(r["Kernel_Name"]) == DELIM:
+            d = r[key] if key else i
+            if d not in seen:
+                seen.add(d)
+                delims.append(int(d) if key else i)
+    n_timed = run["steps"] * run["groups"]
+    if len(delims) < n_timed + 1:
+        raise SystemExit("%s: %d updates in the trace, need more than %d" % (p, len(delims), n_timed))
+    lo, hi = delims[-n_timed - 1], delims[-1]                  # (after the last untimed update, last timed update]
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(p)):
-        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for i, r in enumerate(rows):
+        d = int(r[key]) if key else i
+        if lo < d <= hi:
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
-        if k not in PER_STEP:
-            continue
         o = out["kernels"].setdefault(k, {})
         for c, v in cs.items():
-            tail = v[-PER_STEP[k] * args.steps:]
-            o[c] = sum(tail) / len(tail)
-            o["launches_averaged"] = len(tail)
+            o[c] = sum(v) / len(v)
+            o["launches_averaged"] = len(v)
+            o["launches_per_call"] = len(v) / float(run["steps"])
 for k, o in out["kernels"].items():
     if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
         o["hbm_bytes_per_launch"] = (2.0 * o["FETCH_SIZE"] + o["WRITE_SIZE"]) * 1024.0

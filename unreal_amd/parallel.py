@@ -104,6 +104,22 @@ def sum_over_ranks(values, device):
     return [float(x) for x in t.tolist()]
 
 
+def gather_over_ranks(value, device):
+    """[value of rank 0, rank 1, ...] on every rank (one float per rank).  A SUM all-reduce of a one-hot-placed vector:
+    gloo has no all_gather for device tensors, all_reduce works on both backends."""
+    if not (_active() and dist.get_world_size() > 1):
+        return [float(value)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def world_size():
+    """Ranks of the process group that actually formed (1 without one)."""
+    return dist.get_world_size() if _active() else 1
+
+
 def barrier():
     if _active() and dist.get_world_size() > 1:
         dist.barrier()

@@ -130,6 +130,8 @@ class Trainer(object):
         self.experience = None
         self.last_losses = {}
         self.last_grad_norm = None
+        self.time_grad_sync = False                  # bench.py: time the gradient exchange of every update
+        self._sync_events = []
 
     # ---------------------------------------------------------------------------------------------------
     def prepare(self, termination_time=50.0, termination_dist_value=-10.0):
@@ -598,7 +600,13 @@ class Trainer(object):
             lr = self._anneal_learning_rate(global_t + g * self.Bg * self.n_step_TD * self.world_size)
             self.compute_gradients()
             if self.grad_sync is not None:
+                if self.time_grad_sync:                  # HIP events on the launch stream around the exchange
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.grad_sync(net.grads.flat)           # RCCL all-reduce (sum of per-rank means / world)
+                if self.time_grad_sync:
+                    e1.record()
+                    self._sync_events.append((e0, e1))
             self.last_grad_norm = self.grad_applier.step(net.params.flat, net.grads.flat, lr)
             net.mark_params_changed()
             ops.rollout_stats(self.Bg, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
@@ -611,6 +619,14 @@ class Trainer(object):
         steps, episodes, score_sum = self.read_stats()
         self._publish_losses()
         return steps, (score_sum / episodes if episodes > 0 else None)
+
+    def grad_sync_ms(self):
+        """[ms] of every gradient exchange since the last call (time_grad_sync): from the point the launch stream reaches
+        the all-reduce (the backward kernels before it have drained) to the point it may continue with clip + RMSProp."""
+        torch.cuda.synchronize()
+        out = [e0.elapsed_time(e1) for e0, e1 in self._sync_events]
+        self._sync_events = []
+        return out
 
     def read_stats(self):
         """(env steps, finished episodes, sum of their scores) since the last read; one host sync."""
