@@ -26,8 +26,11 @@ class Evaluate(object):
         self.u, self.actions = z(B, torch.float64), z(B, torch.int32)
         self.rewards, self.terminals = z(B, torch.float32), z(B, torch.int32)
 
-    def process(self, n_episodes, max_episode_steps=2000):
-        """-> dict(episodes, success_rate, mean_return, mean_length, timeouts)"""
+    def process(self, n_episodes, max_episode_steps=2000, one_episode_per_actor=False):
+        """-> dict(episodes, success_rate, mean_return, return_std, mean_length, timeouts).
+        `one_episode_per_actor`: count only the FIRST episode of each of the B lock-step actors and stop when all B have
+        finished or timed out (n_episodes is ignored).  Stopping at the first n finished episodes instead over-represents
+        short episodes whenever actors restart while others are still in their first one."""
         B, A, net, ws, ring = self.B, self.net._action_size, self.net, self.ws, self.env.ring
         net.refresh_shadows()
         self.env.reset()
@@ -37,6 +40,9 @@ class Evaluate(object):
             ws.h0.zero_()
         steps = [0] * B
         done, returns, lengths, successes, timeouts = 0, [], [], 0, 0
+        counted = [False] * B
+        if one_episode_per_actor:
+            n_episodes = B
         while done < n_episodes:
             ring.cur_idx(out=ws.frame_idx[:B])
             net.encode_rows(ring, ws, 0, B, lar_from_ring=False, save_c1=False, lstm_x=False)
@@ -55,13 +61,21 @@ class Evaluate(object):
             term = self.terminals.cpu().numpy()
             score = ring.score_out.cpu().numpy()
             force = torch.zeros(B, dtype=torch.int32)
+            ep_r = None
             for b in range(B):
                 steps[b] += 1
+                skip = one_episode_per_actor and counted[b]
                 if term[b]:
-                    returns.append(float(score[b])); lengths.append(steps[b]); successes += 1; done += 1; steps[b] = 0
+                    if not skip:
+                        returns.append(float(score[b])); lengths.append(steps[b]); successes += 1; done += 1
+                    steps[b] = 0; counted[b] = True
                 elif steps[b] >= max_episode_steps:
-                    timeouts += 1; done += 1; steps[b] = 0; force[b] = 1
-                    returns.append(float(ring.episode_reward.cpu()[b])); lengths.append(max_episode_steps)
+                    if ep_r is None:
+                        ep_r = ring.episode_reward.cpu()
+                    if not skip:
+                        timeouts += 1; done += 1
+                        returns.append(float(ep_r[b])); lengths.append(max_episode_steps)
+                    steps[b] = 0; force[b] = 1; counted[b] = True
             if int(force.sum()):                   # abandon timed-out episodes
                 m = force.to(self.device)
                 self.env.reset(m)
@@ -69,5 +83,7 @@ class Evaluate(object):
                 if net._use_lstm:
                     ops.reset_state(B, m, ws.c0, ws.h0)
         n = len(returns)
-        return dict(episodes=n, success_rate=successes / float(n), mean_return=sum(returns) / n,
+        mean = sum(returns) / n
+        return dict(episodes=n, success_rate=successes / float(n), mean_return=mean,
+                    return_std=(sum((r - mean) ** 2 for r in returns) / n) ** 0.5,
                     mean_length=sum(lengths) / float(n), timeouts=timeouts)
