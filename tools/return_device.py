@@ -60,7 +60,7 @@ def main():
         net.mark_params_changed()
         applier._create_slots(net.params.flat)
         applier.ms.copy_(st["rms"])
-        applier.mom.copy_(st["mom"])
+        applier.mom.zero_()                            # momentum = 0.0 (main.py:240): the slot stays zero, not saved
         global_t, n_eps, calls = int(st["global_t"]), int(st["episodes"]), int(st["calls"])
         tr.draws.counter = int(st["draw_counter"])
         marks = [m for m in marks if m > global_t]
@@ -96,8 +96,10 @@ def main():
             log.flush()
         if args.budget_s and time.time() - t0 > args.budget_s:
             done = True
-    torch.save({"params": net.params.flat.detach().cpu(), "rms": applier.ms.detach().cpu(), "mom": applier.mom.detach().cpu(),
+    torch.save({"params": net.params.flat.detach().cpu(), "rms": applier.ms.detach().cpu(),
                 "global_t": global_t, "episodes": n_eps, "calls": calls, "draw_counter": tr.draws.counter}, state_path)
+    if global_t >= args.steps:             # finished: nothing to resume (the state is 15 MB; gpurun_out travels back with <= 64 MiB)
+        os.remove(state_path)
     log.write(json.dumps({"stopped_at": global_t, "finished": global_t >= args.steps, "elapsed_s": round(time.time() - t0, 1),
                           "steps_per_s": round((global_t - g0) / max(time.time() - t0, 1e-9), 1)}) + "\n")
     log.close()

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
-        ap.add_argument("--cap", type=int, default=2000)
+    ap.add_argument("--cap", type=int, default=2000)
     ap.add_argument("--batch", type=int, default=256)
     args = ap.parse_args()
     from unreal_amd.evaluate import Evaluate

@@ -17,4 +17,8 @@ done
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=$?; done
 tail -n 2 gpurun_out/return/${TAG}_s*/stdout.log
+# evaluate the snapshots here (gpurun_out travels back with <= 64 MiB: the 7.6 MB snapshots do not), then drop them
+dirs=(); for s in "$@"; do dirs+=(gpurun_out/return/${TAG}_s$s); done
+python3 tools/return_eval.py --cap "${CAP:-2000}" "${dirs[@]}" >> gpurun_out/return/eval_${TAG}.jsonl 2> gpurun_out/return/eval_${TAG}.err || { rc=$?; tail -n 20 gpurun_out/return/eval_${TAG}.err; }
+rm -f gpurun_out/return/${TAG}_s*/ckpt-*.npz
 exit $rc

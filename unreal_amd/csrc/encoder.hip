@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
   }
 }
 
-#ifdef UNREAL_ABLATE     // diagnostic build only (tools/exp/ablate_encoder_bwd.py --stamps): where a wave's cycles go
+#ifdef UNREAL_ABLATE     // ---- round-2 backward kernel: kept as the A/B reference of tools/exp/roles_ab.py, not in the product ----
+// diagnostic stamps (tools/exp/ablate_encoder_bwd.py --stamps): where a wave's cycles go
 __device__ unsigned long long g_stamp_sum[4][16];
 #define STAMP(k)                                                                   \
   do {                                                                             \
@@ -450,9 +451,6 @@ __device__ unsigned long long g_stamp_sum[4][16];
       t_prev_ = t_;                                                                \
     }                                                                              \
   } while (0)
-#else
-#define STAMP(k)
-#endif
 
 template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
 __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
@@ -763,6 +761,9 @@ __global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_
     if (lane < 8) atomicAdd(db2 + lane * 4 + e, v);
   }
 }
+#endif   // UNREAL_ABLATE (round-2 backward kernel)
+
+#include "encoder_bwd_roles.h"     // round 3: the role-specialised backward kernel (uses the helpers above)
 
 }  // namespace
 
@@ -787,13 +788,39 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
                        void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W2 || !c1_saved || !d2 || !dW1 || !db1 || !dW2 || !db2)
     return UNREAL_EINVAL;
-  int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
-  hipLaunchKernelGGL(encoder_bwd_kernel<7>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                     frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2);
+  int blocks = min(N, 256);             // one 512-thread workgroup per CU (4 consumer + 4 producer waves), a frame at a time
+  hipLaunchKernelGGL((encoder_bwd_roles_kernel<7, true>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames,
+                     frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2);
   return unreal_launch_status();
 }
 
 #ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
+int exp_encoder_bwd_roles(int variant, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
+                          const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
+                          float* db2, void* stream) {
+  int blocks = min(N, 256);             // one 512-thread workgroup per CU
+#define LAUNCH_R(P2C, P3ALL, ST) hipLaunchKernelGGL((encoder_bwd_roles_kernel<P2C, P3ALL, ST>), dim3(blocks), dim3(512), 0, \
+                                    (hipStream_t)stream, N, frames, frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2)
+  switch (variant) {
+    case 0: LAUNCH_R(7, true, false); break;
+    case 1: LAUNCH_R(6, true, false); break;
+    case 2: LAUNCH_R(5, true, false); break;
+    case 3: LAUNCH_R(7, false, false); break;
+    case 100: LAUNCH_R(7, true, true); break;
+    case 102: LAUNCH_R(5, true, true); break;
+    default: return UNREAL_EINVAL;
+  }
+  return unreal_launch_status();
+}
+int exp_read_rstamps(unsigned long long* host128, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host128, HIP_SYMBOL(g_rstamp), sizeof(unsigned long long) * 128);
+  if (reset) {
+    unsigned long long z[128] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rstamp), z, sizeof(z));
+  }
+  return 0;
+}
 int exp_read_stamps(unsigned long long* host64, int reset) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamp_sum), sizeof(unsigned long long) * 64);

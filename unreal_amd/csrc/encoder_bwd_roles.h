@@ -1,0 +1,550 @@
+// Included by encoder.hip inside its anonymous namespace (uses split4, tr_pair, kdeal, xrow, WG_BARRIER, SPLIT_MMA ...).
+// ------------------------------------------------------------------------------------------------
+// Conv encoder backward, round 3: ROLE-SPECIALISED waves + TABLE-DRIVEN addressing.
+//
+// What round 2's stamps and this round's instruction counts say: the kernel is bound by a wave's own in-order
+// instruction stream, not by the matrix pipe and not by LDS latency.  A wave64 VALU instruction costs the issuing wave
+// 4 cycles, a 16x16x32 MFMA holds its issue for 8 of its 16; round 2 spent ~1,200 VALU per wave and frame -- staging
+// (fp32 -> three bf16 planes, uint8 -> bf16), div / mod / swizzle address arithmetic re-derived for every frame (it
+// had to be: hoisted, the address sets spilled), the dgrad epilogue -- beside 438 MFMAs, so each phase ran at 2.2-4.6x
+// its matrix-pipe time whatever the wave layout (software-pipelining the LDS reads changed nothing).
+//
+// Here: one 512-thread workgroup per CU.  Waves 0-3 ("consumers") run the three MFMA phases and NOTHING else: every
+// LDS address they use comes from per-lane TABLES built once per kernel (two 16-bit offsets per register, ~50
+// registers -- they fit because consumers no longer hold a frame of prefetched operands), so a frame costs them
+// ~440 VALU instead of ~1,100.  Waves 4-7 ("producers", one per SIMD beside a consumer) fetch frame n+1 from HBM into
+// registers, split c1 / d2 into the bf16x3 planes of the OTHER X / Z buffer, expand the uint8 frame to the bf16
+// image, and take half the row tiles of the conv1 wgrad (phase 3), whose operands both waves then read.
+// LDS (162,144 B):  X[2] c1 / d1 planes, 402 rows per plane (row 400 = zeros: K padding of phase 3; row 401 = dump), double-buffered
+//       (frame n is read until the end of its phase 3 while n+1 is staged) | Z[2] d2 planes with their zero halo
+//       (zeroed ONCE: nothing overwrites them any more) | I the bf16 frame image (single: built for frame n between
+//       barriers A(n) and B(n), read by phase 3 of frame n only).
+// Three workgroup barriers per frame (round 2: six), executed by every wave whatever its role:
+//   A(n)  X(n), Z(n) staged; phase 3 of frame n-1 finished            -> phase 1        | producers: image, d2 planes of n+1
+//   S1(n) phase 1 finished reading the c1 planes                       -> phase 2 (d1 overwrites c1) | producers: c1 planes of n+1, loads
+//   B(n)  d1 planes and the image of frame n complete                  -> phase 3 on all waves
+// ------------------------------------------------------------------------------------------------
+#ifdef UNREAL_ABLATE     // diagnostic build only (tools/exp/roles_ab.py --stamps): where a wave's cycles go, per role
+__device__ unsigned long long g_rstamp[8][16];
+#define RSTAMP(k)                                                                  \
+  do {                                                                             \
+    if (STAMPS && blockIdx.x == 3 && lane == 0) {                                  \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
+      g_rstamp[wv][k] += t_ - t_prev_;                                             \
+      t_prev_ = t_;                                                                \
+    }                                                                              \
+  } while (0)
+#else
+#define RSTAMP(k)
+#endif
+
+constexpr int XPLR = (C1_POS + 2) * XROW;          // 12864: plane stride; row 400 = zeros (K padding), row 401 = dump (padding lanes' stores)
+constexpr int R_XSZ = 3 * XPLR;                    // 38496: one X buffer
+constexpr int R_Z = 2 * R_XSZ;                     // 76992
+constexpr int R_I = R_Z + 2 * Z_BYTES;             // 119616
+constexpr int R_LDS = R_I + 2 * FRAME_BYTES;       // 161952
+static_assert(R_LDS <= 160 * 1024, "one workgroup per CU must fit the LDS");
+static_assert(R_XSZ < 65536 && Z_BYTES < 65536 && 2 * FRAME_BYTES < 65536, "table offsets are 16-bit, region-relative");
+
+// X layout of this kernel: position p -> row xrow(p) (as in round 2: 8 consecutive rows AND 8 rows two apart fall into 8
+// different 32-byte slots of the 256-byte bank window) and, new, the four 8-byte channel chunks of a row are stored at
+// chunk position c ^ xchunk(p).  Why: the dgrad epilogue's lane (i, q) holds channels 4q..4q+3 of ONE position, so a
+// 16-lane store group (fixed q, 16 positions two rows apart) hit only 2 of 32 banks with an 8-byte store each: 8-way
+// conflicts on every d1 store (and the producers' plane stores queued behind them: stamps, profiles/r03_encoder_bwd_notes.md).
+// With the rotation the four lanes of a group that share a 32-byte slot use four different chunk positions.
+__device__ __forceinline__ int xchunk(int p) { return ((p >> 2) & 1) | (((p >> 4) & 1) << 1); }
+__device__ __forceinline__ int xoff(int p, int c) { return xrow(p) * XROW + ((c ^ xchunk(p)) & 3) * 8; }
+
+// Interleave directive for one pipelined step: NM x { 1 MFMA, NV VALU, ND LDS operations } in program order, so the next
+// step's address arithmetic and fragment requests (and the dgrad's epilogue) issue in the shadow of this step's MFMAs
+// (an MFMA holds the issue port for 8 of its 16 cycles) instead of in a block of their own between two MFMA blocks.
+#define ILV1(NV, ND)                                     \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     \
+  __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);    \
+  __builtin_amdgcn_sched_group_barrier(0x080, ND, 0);
+#define ILV3(NV, ND) ILV1(NV, ND) ILV1(NV, ND) ILV1(NV, ND)
+#define ILV6(NV, ND) ILV3(NV, ND) ILV3(NV, ND)
+
+#define LO16(x) ((x) & 0xffffu)
+#define HI16(x) ((x) >> 16)
+// keeps a loop-invariant table register from being unpacked outside the frame loop (which would double the tables)
+#define PIN(x) asm volatile("" : "+v"(x))
+
+// ---- tables -------------------------------------------------------------------------------------
+struct P1Tab {
+  uint32_t z[3][2];     // [ks][nt]   lo: d2 block of positions p0.., hi: p0 + 8..   (Z-relative byte offsets)
+  uint32_t x[3][4];     // [ks][kx]   lo / hi: c1 rows of the same positions, tap (ky, kx)   (X-relative)
+};
+struct P2Tab {
+  uint32_t tap[2];      // [tap pair]  lo / hi: d2 halo row of tap 2j / 2j + 1 of position m = i, tile 0 (Z-relative).  Tile t
+                        // is 16 rows = 1024 bytes further (the half-swap of a row depends on bit 2 of its index, which 16
+                        // does not touch): an immediate offset.  Lanes past position 99 of the last tile read beyond the
+                        // halo grid (other LDS bytes): their column of the product is never stored.
+  uint32_t dst[7];      // [tile]  lo: c1 / d1 row of this lane's position (X-relative), bit 31: position < 100
+};
+struct P3Tab {
+  uint32_t b[7];        // [kc]  lo / hi: d1 rows of slots s0.. / s0 + 8..  (X-relative; row 400 = zero for K padding)
+  uint32_t a[7];        // [kc]  lo / hi: patch origins of the same slots in the bf16 image (I-relative)
+};
+
+__device__ __forceinline__ void p1_tab_build(P1Tab& T, int ky, int q, int qq, int pp) {
+#pragma unroll
+  for (int ks = 0; ks < 3; ++ks) {
+    const int p0 = 32 * ks + kdeal(q, qq), p1 = p0 + 8;              // <= 95: K padding reads the zero halo row 0
+    const int z0 = p0 < C2_POS ? (p0 / 9 + 1) * 10 + p0 % 9 + 1 : 0;
+    const int z1 = p1 < C2_POS ? (p1 / 9 + 1) * 10 + p1 % 9 + 1 : 0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const uint32_t o0 = z0 * ZROW + ((4 * nt + pp) ^ (z0 & 4)) * 8, o1 = z1 * ZROW + ((4 * nt + pp) ^ (z1 & 4)) * 8;
+      T.z[ks][nt] = o0 | (o1 << 16);
+    }
+    const int c0 = min(p0, C2_POS - 1), c1i = min(p1, C2_POS - 1);   // K padding: any valid c1 row (the d2 row is 0)
+    const int r0 = (2 * (c0 / 9) + ky) * 20 + 2 * (c0 % 9), r1 = (2 * (c1i / 9) + ky) * 20 + 2 * (c1i % 9);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const uint32_t o0 = xoff(r0 + kx, pp), o1 = xoff(r1 + kx, pp);
+      T.x[ks][kx] = o0 | (o1 << 16);
+    }
+  }
+}
+
+__device__ __forceinline__ void p2_tab_build(P2Tab& T, int par, int i, int q) {
+  uint32_t o[4];
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    const int r = i + 11 - 10 * (dd >> 1) - (dd & 1);                 // halo row of tap (da, db) of position m = i
+    o[dd] = r * ZROW + (q ^ ((r & 4) >> 1)) * 16;
+  }
+  T.tap[0] = o[0] | (o[1] << 16);
+  T.tap[1] = o[2] | (o[3] << 16);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int m = min(16 * t + i, 99);
+    const int ma = m / 10, mb = m - 10 * ma;
+    const int pos = (2 * ma + (par >> 1)) * 20 + 2 * mb + (par & 1);
+    // padding lanes of the last tile (no position): their d1 goes to the dump row 401, their bias weight is 0
+    T.dst[t] = 16 * t + i < 100 ? ((uint32_t)xoff(pos, q) | 0x80000000u) : (uint32_t)((C1_POS + 1) * XROW + 8 * q);
+  }
+}
+
+__device__ __forceinline__ void p3_tab_build(P3Tab& T, int khalf, int q, int qq, int pp) {
+  const int pbase = 200 * khalf;
+#pragma unroll
+  for (int kc = 0; kc < 7; ++kc) {
+    const int s0 = 32 * kc + kdeal(q, qq), s1 = s0 + 8;
+    const uint32_t b0 = s0 < 200 ? xoff(pbase + s0, pp) : C1_POS * XROW + 8 * pp;     // (the zero row: any chunk)
+    const uint32_t b1 = s1 < 200 ? xoff(pbase + s1, pp) : C1_POS * XROW + 8 * pp;
+    T.b[kc] = b0 | (b1 << 16);
+    const int ps0 = pbase + min(s0, 199), ps1 = pbase + min(s1, 199);   // padding slots: any valid address (B = 0)
+    const uint32_t a0 = (4 * (ps0 / 20) * FRAME_ROW_BYTES + 12 * (ps0 % 20)) * 2;
+    const uint32_t a1 = (4 * (ps1 / 20) * FRAME_ROW_BYTES + 12 * (ps1 % 20)) * 2;
+    T.a[kc] = a0 | (a1 << 16);
+  }
+}
+
+// ---- phases -------------------------------------------------------------------------------------
+// (1) conv2 wgrad for one filter row (the table's ky), both n-tiles: 12 steps (ks, kx); the c1 fragments of step
+// s + 1 and the d2 fragments of the next ks are requested before the MFMAs of step s
+__device__ __forceinline__ void bwd_phase1_t(const unsigned char* xp, const unsigned char* zp, P1Tab& T, f32x4 (&aw2)[4][2]) {
+  bf16x8 bf[2][3];                 // d2 fragments of the current ks (re-requested behind the last MFMAs that read them:
+                                   // two ~LDS-latency bubbles per frame instead of 24 more registers)
+  bf16x8 af[2][3];                 // c1 fragments of step s, by parity of s
+  auto load_bf = [&](int ks) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      PIN(T.z[ks][nt]);
+      const unsigned char* b0 = zp + LO16(T.z[ks][nt]);
+      const unsigned char* b1 = zp + HI16(T.z[ks][nt]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) bf[nt][t] = tr_pair(b0 + t * ZPL, b1 + t * ZPL);
+    }
+  };
+  auto load_af = [&](int s) {
+    PIN(T.x[s >> 2][s & 3]);
+    const unsigned char* a0 = xp + LO16(T.x[s >> 2][s & 3]);
+    const unsigned char* a1 = xp + HI16(T.x[s >> 2][s & 3]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) af[s & 1][t] = tr_pair(a0 + t * XPLR, a1 + t * XPLR);
+  };
+  load_bf(0);
+  load_af(0);
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const int ks = s >> 2, kx = s & 3;
+    if (s + 1 < 12) load_af(s + 1);
+    SPLIT_MMA(af[s & 1], bf[0], aw2[kx][0]);
+    SPLIT_MMA(af[s & 1], bf[1], aw2[kx][1]);
+    ILV6(1, 1) ILV6(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (kx == 3 && ks < 2) load_bf(ks + 1);
+  }
+}
+
+// (2) conv2 dgrad for the table's output parity, position tiles [T0, T1): d1 planes written over the c1 planes in
+// place.  Steps = (tile, tap); one fragment set per tap (4 sets), the set of the step three ahead is requested before a
+// step's MFMAs.  The epilogue of tile t (ReLU mask from the c1 hi terms, split into the three planes, stores, bias
+// sums) is issued under the MFMAs of tile t + 1.
+template <int T0, int T1>
+__device__ __forceinline__ void bwd_phase2_t(unsigned char* xp, const unsigned char* zp, P2Tab& T, const bf16x8 (&wa)[4][3],
+                                             float (&adb1)[4]) {
+  bf16x8 f[4][3];
+  auto load_tap = [&](int t, int dd) {
+    if (dd == 0 || dd == 2) PIN(T.tap[dd >> 1]);
+    const unsigned char* zt = zp + ((dd & 1) ? HI16(T.tap[dd >> 1]) : LO16(T.tap[dd >> 1]));
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) f[dd][pl] = *reinterpret_cast<const bf16x8*>(zt + t * (16 * ZROW) + pl * ZPL);
+  };
+  auto epi_mask = [&](int t, const f32x4& acc, unsigned char*& dst, f32x4& g) {
+    PIN(T.dst[t]);
+    dst = xp + LO16(T.dst[t]);
+    const u32x2v hi = *reinterpret_cast<const u32x2v*>(dst);
+    g[0] = (hi[0] & 0xffffu) ? acc[0] : 0.f;        // (the dump row's "hi" is whatever was dumped last: harmless)
+    g[1] = (hi[0] >> 16) ? acc[1] : 0.f;
+    g[2] = (hi[1] & 0xffffu) ? acc[2] : 0.f;
+    g[3] = (hi[1] >> 16) ? acc[3] : 0.f;
+  };
+  // BRANCH-FREE (an exec-masked block would sit behind the tap's MFMAs instead of between them): padding lanes store to
+  // the dump row and add 0 to the bias sums
+  auto epi_store = [&](int t, unsigned char* dst, const f32x4& g) {
+    u32x2v pl[3];
+    split4(g, pl);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x2v*>(dst + u * XPLR) = pl[u];
+    const float w = (int)T.dst[t] < 0 ? 1.f : 0.f;      // bit 31: a live position
+#pragma unroll
+    for (int e = 0; e < 4; ++e) adb1[e] = fmaf(w, g[e], adb1[e]);
+  };
+  load_tap(T0, 0);
+  load_tap(T0, 1);
+  load_tap(T0, 2);
+  f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = T0; t < T1; ++t) {
+    const int tn = t + 1 < T1 ? t + 1 : t;                   // (the last tile re-requests its own fragments: unused)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned char* dst = xp;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#ifdef EXP_P2_NOLOAD      // timing experiments only (results wrong)
+#define LT(a, b) do { if (t == T0) load_tap(a, b); } while (0)
+#else
+#define LT(a, b) load_tap(a, b)
+#endif
+#ifdef EXP_P2_NOEPI
+#define EPI_ON false
+#else
+#define EPI_ON true
+#endif
+    LT(t, 3);
+    SPLIT_MMA(wa[0], f[0], acc);
+    if (EPI_ON && t > T0) epi_mask(t - 1, prev, dst, g);
+    ILV6(3, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    LT(tn, 0);
+    SPLIT_MMA(wa[1], f[1], acc);
+    if (EPI_ON && t > T0) epi_store(t - 1, dst, g);
+    ILV6(6, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    LT(tn, 1);
+    SPLIT_MMA(wa[2], f[2], acc);
+    ILV6(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    LT(tn, 2);
+    SPLIT_MMA(wa[3], f[3], acc);
+    ILV6(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    prev = acc;
+  }
+  unsigned char* dst;
+  f32x4 g;
+  epi_mask(T1 - 1, prev, dst, g);
+  epi_store(T1 - 1, dst, g);
+}
+
+// (3) conv1 wgrad: NT3 row tiles (toff) over the table's 200 positions as 7 steps of 32 slots; the fragments of step
+// kc + 1 are requested before the MFMAs of step kc
+template <int NT3>
+__device__ __forceinline__ void bwd_phase3_t(const unsigned char* xp, const unsigned char* ip, P3Tab& T, const int (&toff)[NT3],
+                                             f32x4 (&aw1)[NT3]) {
+  bf16x8 bpl[2][3], av[2][NT3];
+  auto load_step = [&](int kc) {
+    PIN(T.b[kc]);
+    PIN(T.a[kc]);
+    const unsigned char* b0 = xp + LO16(T.b[kc]);
+    const unsigned char* b1 = xp + HI16(T.b[kc]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bpl[kc & 1][t] = tr_pair(b0 + t * XPLR, b1 + t * XPLR);
+    const unsigned char* a0 = ip + LO16(T.a[kc]);
+    const unsigned char* a1 = ip + HI16(T.a[kc]);
+#pragma unroll
+    for (int u = 0; u < NT3; ++u) av[kc & 1][u] = tr_pair(a0 + toff[u], a1 + toff[u]);
+  };
+  load_step(0);
+#pragma unroll
+  for (int kc = 0; kc < 7; ++kc) {
+    if (kc + 1 < 7) load_step(kc + 1);
+#pragma unroll
+    for (int u = 0; u < NT3; ++u) {
+      aw1[u] = MFMA_BF16(av[kc & 1][u], bpl[kc & 1][2], aw1[u]);
+      aw1[u] = MFMA_BF16(av[kc & 1][u], bpl[kc & 1][1], aw1[u]);
+      aw1[u] = MFMA_BF16(av[kc & 1][u], bpl[kc & 1][0], aw1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NT3; ++u) { ILV3(1, 2) }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ---- producers' staging ---------------------------------------------------------------------------
+// Every staging step consumes one 16-byte register piece of the frame being staged and immediately re-issues the load of
+// the same piece of the frame after it (`next`, nullptr at the tail): the 16 global loads of a frame are spread over
+// the staging work instead of being issued back to back -- a wave that issues them in a burst sits blocked in the
+// issue stage for ~300 cycles per load while the memory pipeline drains (57 KB per frame and CU is HBM-rate-bound) and
+// can do none of its VALU work meanwhile (stamps: 5,000 of a producer's 14,000 cycles per frame).
+// BRANCH-FREE on purpose: behind a conditional load hipcc's wait-count pass falls back to s_waitcnt vmcnt(0), which also
+// waits for the loads issued a moment ago -- the HBM latency would be exposed once per piece.  So every step stages and
+// loads unconditionally: threads past the end of a tensor redo piece `tid` (same bytes to the same address), callers
+// pass a valid `next` even at the tail (any frame: the pieces are never staged).
+__device__ __forceinline__ void stage_c1_planes_r(unsigned char* xp, int tid, f32x4 (&pc1)[C1_V], const float* next) {
+#pragma unroll
+  for (int c = 0; c < C1_V; ++c) {
+    const int id0 = tid + 256 * c, id = id0 < C1_POS * 4 ? id0 : tid;
+    u32x2v pl[3];
+    split4(pc1[c], pl);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPLR + xoff(id >> 2, id & 3)) = pl[t];
+#ifndef EXP_NOLOAD_C1
+    pc1[c] = reinterpret_cast<const f32x4*>(next)[id];
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// d2 planes of one frame (no halo: the halo rows of both Z buffers are zeroed once per kernel)
+__device__ __forceinline__ void stage_d2_planes_r(unsigned char* zp, int tid, f32x4 (&pd2)[D2_V], float (&adb2)[4], const float* next,
+                                                  float count) {
+#pragma unroll
+  for (int c = 0; c < D2_V; ++c) {
+    const int id0 = tid + 256 * c, id = id0 < C2_POS * 8 ? id0 : tid;
+    u32x2v pl[3];
+    split4(pd2[c], pl);
+    const int pos = id >> 3, r = (pos / 9 + 1) * 10 + pos % 9 + 1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2v*>(zp + t * ZPL + r * ZROW + ((id & 7) ^ (r & 4)) * 8) = pl[t];
+    const float w = id0 < C2_POS * 8 ? count : 0.f;       // bias gradient: every element once, frames that exist only
+#pragma unroll
+    for (int e = 0; e < 4; ++e) adb2[e] = fmaf(w, pd2[c][e], adb2[e]);
+#ifndef EXP_NOLOAD_D2
+    pd2[c] = reinterpret_cast<const f32x4*>(next)[id];
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// uint8 frame (16-byte pieces in registers) -> bf16 image [84][252]: a byte is exact in bf16
+__device__ __forceinline__ void build_image_r(unsigned char* ip, int tid, u32x4 (&raw)[FR_V], const uint8_t* next) {
+#pragma unroll
+  for (int k = 0; k < FR_V; ++k) {
+    const int c = min(tid + 256 * k, FR_CHUNKS - 1);
+    u32x4 o[2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t w = raw[k][d];
+      const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu),
+                  f3 = (float)(w >> 24);
+      o[d >> 1][2 * (d & 1)] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+      o[d >> 1][2 * (d & 1) + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
+    }
+    *reinterpret_cast<u32x4*>(ip + 32 * c) = o[0];
+    *reinterpret_cast<u32x4*>(ip + 32 * c + 16) = o[1];
+#ifndef EXP_NOLOAD_U8
+    raw[k] = reinterpret_cast<const u32x4*>(next)[c];
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// P2C: position tiles of phase (2) the consumers take (7 = all; the producers take [P2C, 7) of the same parity).
+// P3ALL: the producers take half the row tiles of phase (3).
+template <int P2C, bool P3ALL, bool STAMPS = false>
+__global__ __launch_bounds__(512, 2) void encoder_bwd_roles_kernel(int N, const uint8_t* __restrict__ frames,
+                                                                   const int* __restrict__ frame_idx, float scale,
+                                                                   const float* __restrict__ W2,
+                                                                   const float* __restrict__ c1_saved,
+                                                                   const float* __restrict__ d2_in,
+                                                                   float* __restrict__ dW1, float* __restrict__ db1,
+                                                                   float* __restrict__ dW2, float* __restrict__ db2) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[R_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..7, wave-uniform
+  const bool consumer = wv < 4;
+  const int gw = wv & 3, t256 = tid & 255;
+  const int i = lane & 15, q = lane >> 4;
+  const int qq = i >> 2, pp = i & 3;
+  unsigned char* const ip = smem + R_I;
+  constexpr int NT3 = P3ALL ? 3 : 6;           // row tiles of phase (3) per wave
+  constexpr bool P2SPLIT = P2C < 7;
+  // phase (3): 12 row tiles x 2 position halves = 8 x (3 tiles, half) or 4 x (6 tiles, half)
+  const int tset = P3ALL ? (wv & 3) : (gw & 1), khalf = P3ALL ? (wv >> 2) : (gw >> 1);
+
+  // once: the zero row of every X plane and the halo rows of both Z buffers
+  if (tid < 2 * 3 * 8) *reinterpret_cast<uint32_t*>(smem + (tid / 24) * R_XSZ + ((tid / 8) % 3) * XPLR + C1_POS * XROW + (tid & 7) * 4) = 0u;
+  for (int e = tid; e < 2 * 3 * Z_HALO * 4; e += 512) {
+    const int buf = e / (3 * Z_HALO * 4), e1 = e % (3 * Z_HALO * 4);
+    const int t = e1 / (Z_HALO * 4), k = (e1 >> 2) % Z_HALO;
+    const int r = k < 10 ? k : (k < 19 ? (k - 9) * 10 : 81 + k);
+    *reinterpret_cast<u32x4*>(smem + R_Z + buf * Z_BYTES + t * ZPL + r * ZROW + (e1 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  }
+
+  f32x4 aw2[4][2];
+  f32x4 aw1[NT3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) aw2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < NT3; ++a) aw1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int toff[NT3];
+#pragma unroll
+  for (int u = 0; u < NT3; ++u) {
+    const int m0 = 16 * (NT3 * tset + u) + 4 * pp;
+    toff[u] = ((m0 / 24) * FRAME_ROW_BYTES + (m0 % 24)) * 2;
+  }
+  float adb1[4] = {0.f, 0.f, 0.f, 0.f};   // phase (2) waves: channel 4q + e
+  float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // producers: n = (t256 % 8) * 4 + e
+
+  const int stride = gridDim.x;
+  const int trip = (N - (int)blockIdx.x + stride - 1) / stride;       // the launch guarantees gridDim.x <= N
+
+  // W2 fragments of phase (2), once per kernel: wave gw (and its producer partner) owns output parity (gw>>1, gw&1)
+  bf16x8 wa[4][3];
+  P2Tab T2;
+  if (consumer || P2SPLIT) {
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      const int ky = (gw >> 1) + 2 * (dd >> 1), kx = (gw & 1) + 2 * (dd & 1);
+      const f32x4* wsrc = reinterpret_cast<const f32x4*>(W2 + ((ky * 4 + kx) * 16 + i) * 32 + 8 * q);
+      u32x2v lo[3], hi[3];
+      split4(wsrc[0], lo);
+      split4(wsrc[1], hi);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+        wa[dd][t] = __builtin_bit_cast(bf16x8, w4);
+      }
+    }
+    p2_tab_build(T2, gw, i, q);
+  }
+  P3Tab T3;
+  if (consumer || P3ALL) p3_tab_build(T3, khalf, q, qq, pp);
+
+#ifdef UNREAL_ABLATE
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  if (consumer) {
+    P1Tab T1;
+    p1_tab_build(T1, gw, q, qq, pp);
+    for (int k = 0; k < trip; ++k) {
+      unsigned char* xp = smem + (k & 1) * R_XSZ;
+      const unsigned char* zp = smem + R_Z + (k & 1) * Z_BYTES;
+      RSTAMP(0);
+      WG_BARRIER();     // A(n)
+      RSTAMP(1);        // wait at A
+      bwd_phase1_t(xp, zp, T1, aw2);
+      RSTAMP(2);        // phase 1
+      WG_BARRIER();     // S1(n)
+      RSTAMP(3);        // wait at S1
+      bwd_phase2_t<0, P2C>(xp, zp, T2, wa, adb1);
+      RSTAMP(4);        // phase 2
+      WG_BARRIER();     // B(n)
+      RSTAMP(5);        // wait at B
+      bwd_phase3_t<NT3>(xp, ip, T3, toff, aw1);
+      RSTAMP(6);        // phase 3
+    }
+  } else {
+    // producers: registers U (uint8 frame), C (c1), D (d2) of the frames ahead.  At barrier A(n): U = frame n,
+    // C = D = frame n + 1 (fetched while frame n - 1 was staged); every piece is re-fetched for the frame after as it is used
+    u32x4 ur[FR_V];
+    f32x4 pc1[C1_V], pd2[D2_V];
+    auto c1_of = [&](int n) { return c1_saved + (size_t)n * (C1_POS * C1_CH); };
+    auto d2_of = [&](int n) { return d2_in + (size_t)n * F2_DIM; };
+    {
+      const int n0 = blockIdx.x, n1 = n0 + stride;
+#pragma unroll
+      for (int c = 0; c < C1_V; ++c) pc1[c] = reinterpret_cast<const f32x4*>(c1_of(n0))[t256 + 256 * c < C1_POS * 4 ? t256 + 256 * c : t256];
+#pragma unroll
+      for (int c = 0; c < D2_V; ++c) pd2[c] = reinterpret_cast<const f32x4*>(d2_of(n0))[t256 + 256 * c < C2_POS * 8 ? t256 + 256 * c : t256];
+      const u32x4* usrc = reinterpret_cast<const u32x4*>(frames + (size_t)frame_idx[n0] * FRAME_BYTES);
+#pragma unroll
+      for (int c = 0; c < FR_V; ++c) ur[c] = usrc[min(t256 + 256 * c, FR_CHUNKS - 1)];
+      const int n1c = n1 < N ? n1 : n0;
+      stage_c1_planes_r(smem, t256, pc1, c1_of(n1c));
+      stage_d2_planes_r(smem + R_Z, t256, pd2, adb2, d2_of(n1c), 1.f);
+    }
+    int fidx_next = frame_idx[min((int)blockIdx.x + stride, N - 1)];      // one iteration ahead (clamped at the tail)
+    for (int k = 0; k < trip; ++k) {
+      const int n = blockIdx.x + k * stride, nn = n + stride, nnn = nn + stride;
+      const bool has_next = nn < N;
+      const int nnn_c = nnn < N ? nnn : n;                     // tail: any valid frame, its pieces are never staged
+      unsigned char* xp = smem + (k & 1) * R_XSZ;
+      const unsigned char* zp = smem + R_Z + (k & 1) * Z_BYTES;
+      unsigned char* xn = smem + ((k + 1) & 1) * R_XSZ;        // (staged unconditionally: at the tail nobody reads them)
+      unsigned char* zn = smem + R_Z + ((k + 1) & 1) * Z_BYTES;
+      RSTAMP(0);
+      WG_BARRIER();     // A(n): phase 3 of frame n-1 finished -> the image buffer and X / Z of frame n-1 are free
+      RSTAMP(1);        // wait at A
+      build_image_r(ip, t256, ur, frames + (size_t)fidx_next * FRAME_BYTES);
+      RSTAMP(7);        // image
+      stage_d2_planes_r(zn, t256, pd2, adb2, d2_of(nnn_c), has_next ? 1.f : 0.f);
+      RSTAMP(9);        // d2 planes
+      WG_BARRIER();     // S1(n)
+      RSTAMP(3);        // wait at S1
+      stage_c1_planes_r(xn, t256, pc1, c1_of(nnn_c));
+      RSTAMP(8);        // c1 planes
+      if (P2SPLIT) bwd_phase2_t<P2C, 7>(xp, zp, T2, wa, adb1);
+      RSTAMP(4);        // phase 2 share
+      fidx_next = frame_idx[min(nnn, N - 1)];
+      WG_BARRIER();     // B(n)
+      RSTAMP(5);        // wait at B
+      if (P3ALL) bwd_phase3_t<NT3>(xp, ip, T3, toff, aw1);
+      RSTAMP(6);        // phase 3 share
+    }
+  }
+
+  // flush accumulators (C/D map of the 16x16 MFMAs: col = lane & 15, row = 4 * (lane >> 4) + r)
+  if (consumer) {
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(dW2 + ((gw * 4 + kx) * 16 + 4 * q + r) * 32 + nt * 16 + i, aw2[kx][nt][r]);
+  }
+  if (consumer || P3ALL) {
+#pragma unroll
+    for (int u = 0; u < NT3; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * (NT3 * tset + u) + 4 * q + r) * 16 + i, scale * aw1[u][r]);
+  }
+  if (consumer || P2SPLIT) {       // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = adb1[e];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (i == 0) atomicAdd(db1 + 4 * q + e, v);
+    }
+  }
+  if (!consumer) {                 // db2: threads with equal (t256 % 8) own the same 4 columns
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = adb2[e];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 8) atomicAdd(db2 + lane * 4 + e, v);
+    }
+  }
+}
