@@ -124,7 +124,7 @@ int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float
                        float* f2_out /*[N][2592]*/,
                        uint16_t* relu_bits /*nullable [N][81][2]: bit c of word [n][pos][h] = f2[n][pos][16h + c] > 0,
                                              i.e. bit (j % 16) of word j / 16 of row n; UNREAL_GEMM_RELU_BITS reads it */,
-                       void* stream);
+                       float* f2_absmax /*nullable absmax slot: max of f2_out, see unreal_absmax_f32*/, void* stream);
 int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,
                        const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2, float* db2,
                        void* stream);
@@ -133,13 +133,21 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
 int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,
                     int ldb, float* C, int ldc, const float* bias, const float* mask, int ldm, int flags,
                     int splitk, void* stream);
-/* C = A[M,K] * W[N,K]^T with fp32-grade error on the bf16 matrix cores: every operand element is split into three
- * bf16 terms (exact residuals) and six term-pair MFMAs are accumulated in fp32 (csrc/gemm_split.hip).  A is fp32;
- * W3 is the weight matrix as a pre-split shadow made by unreal_split_bf16x3: plane t at W3 + t*plane_stride, row n
- * at + n*ldw (ldw a multiple of 8 and >= K rounded up to 32, padding zero).  Same epilogue flags as
- * unreal_gemm_f32 except ATOMIC.  Used for the forward and dgrad GEMMs of the dense layers. */
-int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw,
-                             long plane_stride, float* C, int ldc, const float* bias,
+/* "absmax slot" = one float in device memory holding max |x| over a tensor (0-initialised by the caller; producers
+ * max their outputs into it atomically).  The fp16x2 GEMMs below derive each operand's power-of-two scale from it, so
+ * the slot handed to a GEMM must cover every element the GEMM reads (a larger value only costs precision).
+ * unreal_absmax_f32 is the stand-alone reduction: slot = max(slot, max |x[r][c]|). */
+int unreal_absmax_f32(int rows, int cols, const float* x, int ld, float* slot, void* stream);
+/* C = A[M,K] * W[N,K]^T with fp32-grade error on the 16-bit matrix cores (csrc/gemm_split.hip, round 3): each operand
+ * is x * 2^k = hi + lo with hi, lo fp16 (k per TENSOR, from its absmax slot), the three term pairs hh, hl, lh are
+ * accumulated in fp32 on v_mfma_f32_32x32x16_f16 and un-scaled exactly.  A is fp32; W2 is the weight matrix as a
+ * pre-split shadow made by unreal_split_f16x2 with the SAME w_absmax slot: plane t (0 = hi, 1 = lo) at
+ * W2 + t*plane_stride, row n at + n*ldw (ldw a multiple of 8 and >= K rounded up to 32, padding zero).  c_absmax
+ * (nullable): receives max |C| of what this call stores.  Same epilogue flags as unreal_gemm_f32 except ATOMIC.  Used
+ * for the forward and dgrad GEMMs of the dense layers (tf.matmul call sites model/model.py:314,334,423). */
+int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W2,
+                             int ldw, long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax,
+                             const float* bias,
                              const void* mask /* fp32 [M][ldm] (RELU_MASK: keep where > 0) or uint16 bit words [M][ldm]
                                                  (RELU_BITS: keep column j where bit j % 16 of word j / 16 is set) */,
                              int ldm, int flags, int splitk, void* stream);
@@ -151,13 +159,21 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
  * lda, ldb multiples of 4 and A, B 16-byte aligned (else -22: use unreal_gemm_f32 transA=1).
  * colsum (nullable): colsum[n] += sum_k B[k][n], the bias gradient that belongs to this weight gradient, summed
  * from the B tiles the kernel stages anyway (saves a separate pass over B). */
-int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                             float* colsum, int splitk, void* stream);
+/* a_absmax / b_absmax: absmax slots covering A and B (both are split as fp16 hi + lo like the NT operands; the MFMA
+ * accumulators are flushed into a second fp32 set every 8 K tiles, which keeps the error under the fp32-MFMA kernel's at
+ * K = 81,920). */
+int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* a_absmax, const float* B, int ldb,
+                             const float* b_absmax, float* C, int ldc, float* colsum, int splitk, void* stream);
 /* bf16x3 shadow of a weight matrix src[rows][cols]: dst[t][r][c] (transpose = 0) or dst[t][c][r] (transpose = 1),
  * t = 0..2 the bf16 terms (sum of the three == src to 2^-24 relative).  dst padding is left untouched (zero it once).
- * Refreshed after every RMSProp step / checkpoint restore. */
+ * (The round-2 operand format; the trainer's shadows are fp16x2 now.) */
 int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
                         int ld_dst, long plane_stride, void* stream);
+/* fp16x2 shadow: dst[0] = hi, dst[1] = lo of src * 2^k, k from w_absmax (a slot that already holds max |src| over the
+ * WHOLE matrix the consuming GEMM multiplies by).  Same layouts / row_perm as above.  Refreshed after every RMSProp step /
+ * checkpoint restore. */
+int unreal_split_f16x2(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
+                       int ld_dst, long plane_stride, const float* w_absmax, void* stream);
 /* row_perm = 1 (1024 output rows only): LSTM gate interleave, output row of column n = g*256 + u of the kernel is
  * (u/16)*64 + g*16 + u%16, the layout unreal_lstm_step_fwd multiplies by. */
 /* One BasicLSTMCell step (model/model.py:110,346-351; gates i,j,f,o, forget_bias 1) on the split-operand path with the
@@ -168,20 +184,26 @@ int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int tr
  *   x != NULL: the cell's own product [x | h_prev] @ kernel in ONE launch (a rollout step, where the input half cannot
  *              be hoisted): x[rows][Kx] (row stride ldx), W3 = gate-interleaved shadow of the WHOLE kernel,
  *              [1024][pad32(Kx) + 256]: columns [0, Kx) the input rows, zeros up to pad32(Kx), then the recurrent rows. */
-int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* h_prev, int ld_hprev, const uint16_t* W3,
-                         int ldw, long plane_stride, float* gates, const float* bias, const float* c_prev, float* c_out,
-                         float* h_out, int ld_h, void* stream);
+/* x_absmax: slot covering x[rows][Kx] (required when x != NULL; |h_prev| < 1 is covered by the kernel itself);
+ * w_absmax: the slot the shadow was made with. */
+int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* x_absmax, const float* h_prev, int ld_hprev,
+                         const uint16_t* W2, int ldw, long plane_stride, const float* w_absmax, float* gates,
+                         const float* bias, const float* c_prev, float* c_out, float* h_out, int ld_h, void* stream);
 /* BPTT through one recurrence step, fused: dh_rec = d_gates[rows,1024] (step t) * Wh^T on the split-operand path
  * (Wh3 = natural-layout shadow of the kernel's recurrent rows, [256][1024]), and in the same launch the gate backward
  * of step t-1 with dh = dh_above + dh_rec: dpre (d_gates of step t-1), dc_io in/out.  Same arithmetic and order as
  * unreal_gemm_f32_split_nt followed by unreal_lstm_gates_bwd (bit-identical), without materialising dh_rec. */
-int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, int ldw, long plane_stride,
-                          const float* dh_above, float* dc_io, const float* gates_act, const float* c_prev,
-                          const float* c_new, float* dpre, void* stream);
+/* a_absmax: slot covering d_gates; dpre_absmax0 / 1 (nullable): receive max |dpre| (the next step's a_absmax, and the
+ * slot of the whole sequence that the fc dgrad reads). */
+int unreal_lstm_bptt_step(int rows, const float* d_gates, const float* a_absmax, const uint16_t* Wh2, int ldw,
+                          long plane_stride, const float* w_absmax, const float* dh_above, float* dc_io,
+                          const float* gates_act, const float* c_prev, const float* c_new, float* dpre,
+                          float* dpre_absmax0, float* dpre_absmax1, void* stream);
 int unreal_lstm_gates_fwd(int rows, const float* pre, const float* bias, const float* c_prev, float* gates_act,
                           float* c_out, float* h_out, int ld_h, void* stream);
 int unreal_lstm_gates_bwd(int rows, const float* dh_above, const float* dh_rec, float* dc_io, const float* gates_act,
-                          const float* c_prev, const float* c_new, float* dpre, void* stream);
+                          const float* c_prev, const float* c_new, float* dpre, float* dpre_absmax0 /*nullable*/,
+                          float* dpre_absmax1 /*nullable*/, void* stream);
 
 /* ---- heads, sampling, losses (model/model.py:358-377, 473-516, 559-576; train/trainer.py:147-148) -- */
 int unreal_linear_small_fwd(int rows, int K, int NOUT, const float* X, int ldx, const float* W, const float* b,
@@ -211,7 +233,8 @@ int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const f
                          const float* ba, float* qmax, const int* action, const float* target, const int* mask,
                          float lambda, float grad_scale, float* d_dec, float* loss, void* stream);
 int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, const float* Wv, const float* Wa,
-                         float* d_hp, float* dWv, float* dbv, float* dWa, float* dba, void* stream);
+                         float* d_hp, float* dhp_absmax /*nullable absmax slot: max |d_hp|*/, float* dWv, float* dbv,
+                         float* dWa, float* dba, void* stream);
 
 /* ---- optimiser (train/rmsprop_applier.py:38-43, 83-93, 121) ---------------------------------------- */
 int unreal_grad_norm(const float* grad, long n, float* scratch /*256 floats*/, float* norm_out, void* stream);

@@ -29,10 +29,15 @@ def test_split_gemm_matches_fp64(M, N, K):
     W = ops.SplitWeights(Bd, N, K, ldb, transpose=False)
     Wt = ops.SplitWeights(dev(B[:, :K].T), K, N, N, transpose=True)          # same matrix from its transpose
     assert torch.equal(W.planes, Wt.planes)
-    pl = W.planes.view(torch.bfloat16).view(3, N, W.ldw).double().cpu().numpy()
+    # fp16x2 shadow: hi + lo of w * 2^k, k = the power of two that puts max |w| into [2^14, 2^15) (read from the absmax slot)
+    pl = W.planes.view(torch.float16).view(2, N, W.ldw).double().cpu().numpy()
     np.testing.assert_array_equal(pl[:, :, K:], 0)
     Bf = B[:, :K].astype(np.float32).astype(np.float64)
-    assert np.abs(pl.sum(0)[:, :K] - Bf).max() <= 2.0 ** -23 * np.abs(Bf).max()   # the three terms rebuild the fp32 value
+    wmax = float(W.wmax.cpu()[0])
+    assert wmax == np.abs(Bf).max()
+    sw = 2.0 ** (14 - np.floor(np.log2(wmax)))
+    assert 2.0 ** 14 <= wmax * sw < 2.0 ** 15
+    assert np.abs(pl.sum(0)[:, :K] / sw - Bf).max() <= 2.0 ** -21 * np.abs(Bf).max()   # hi + lo rebuild 22 bits of the largest element
     ops.gemm_split_nt(M, N, K, dev(A), lda, W, C, ldc, bias=dev(bias))
     got = C[:, :N].cpu().double().numpy()
     err = np.abs(got - (ref + bias))

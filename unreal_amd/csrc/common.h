@@ -31,6 +31,36 @@ static inline int unreal_launch_status() {
   return e == hipSuccess ? UNREAL_OK : UNREAL_ELAUNCH;
 }
 
+// ---- fp16 hi + lo operands (gemm_split.hip): per-tensor power-of-two scales -------------------------------------
+// An "absmax slot" is one float in device memory holding max |x| over a tensor.  Producers commit their outputs' maximum
+// with ONE atomic per wave (non-negative floats order like unsigned integers); consumers turn it into the power of two
+// that puts the largest element into [2^14, 2^15) -- inside fp16's range with a factor two to spare, and deep enough that
+// hi + lo carry 22 significant bits for every element down to 2^-17 of the maximum.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Tens of thousands of waves committing to ONE address would serialise at ~12 ns per atomic (0.6 ms for the 13 k
+// workgroups of a big GEMM), so a wave first reads the slot past its L1 (agent-scope relaxed load: the L2 that also
+// executes the atomic) and only issues the atomic when it would raise the value -- the number of atomics is then the
+// number of running-maximum records (~log of the wave count).  A stale read can only cause a redundant atomic.
+__device__ __forceinline__ void absmax_commit(float* slot, float m) {      // m >= 0; call with the whole wave active
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && slot) {
+    unsigned int* s = reinterpret_cast<unsigned int*>(slot);
+    const unsigned int cur = __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__float_as_uint(m) > cur) atomicMax(s, __float_as_uint(m));
+  }
+}
+// scale = 2^(14 - floor(log2 m)) (1 for m == 0 / subnormal / inf / nan); inverse exact
+__device__ __forceinline__ float pow2_scale(float m) {
+  const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);           // biased exponent of m
+  const int se = (e == 0 || e == 255) ? 127 : min(max(268 - e, 27), 227);
+  return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float pow2_inv(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

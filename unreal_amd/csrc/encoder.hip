@@ -314,8 +314,9 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
                                                              const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2,
                                                              float* __restrict__ c1_out, float* __restrict__ f2_out,
-                                                             uint16_t* __restrict__ relu_bits) {
+                                                             uint16_t* __restrict__ relu_bits, float* f2_absmax) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
+  float f2_max = 0.f;                          // max of the outputs this lane has stored (they are >= 0)
   const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   uint8_t* fr = smem;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
           const int pos = 16 * mt + 4 * q + r;
           const float v = fmaxf((acc[mt][r] + part[r]) + bias2, 0.f);
           if (pos < C2_POS) dst[pos * C2_CH] = v;
+          f2_max = fmaxf(f2_max, pos < C2_POS ? v : 0.f);
           if (BITS) {
             // ReLU pattern of the 16 channels this wave holds of 4 positions: ballot bit 16q + i = (position 4q + r of the
             // tile, channel 16nt + i); the dgrad of the layer above reads 1 bit per element instead of the fp32 output
@@ -438,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       }
     }
   }
+  absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)
 }
 
 #ifdef UNREAL_ABLATE     // ---- round-2 backward kernel: kept as the A/B reference of tools/exp/roles_ab.py, not in the product ----
@@ -771,15 +774,15 @@ extern "C" {
 
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
                        const float* b1, const float* W2, const float* b2, float* c1_out, float* f2_out,
-                       uint16_t* relu_bits, void* stream) {
+                       uint16_t* relu_bits, float* f2_absmax, void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W1 || !b1 || !W2 || !b2 || !f2_out) return UNREAL_EINVAL;
   int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
   if (relu_bits)
     hipLaunchKernelGGL(encoder_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax);
   else
     hipLaunchKernelGGL(encoder_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax);
   return unreal_launch_status();
 }
 

@@ -1,4 +1,6 @@
-// fp32-equivalent GEMM on the bf16 matrix cores of gfx950 ("split-operand", 3 x bf16):
+// fp32-equivalent GEMMs on the 16-bit matrix cores of gfx950 ("split-operand").  Two operand formats:
+//   round 3 (all kernels): fp16 hi + lo with ONE power-of-two scale per tensor, 3 term pairs (see "fp16x2" below)
+//   round 2 (SPLIT_NT_MODE / SPLIT_TN_MODE 0, kept for A/B): 3 x bf16, 6 term pairs, described first:
 //
 //   C[M,N] = A[M,K] * W[N,K]^T (+ bias) (ReLU) (ReLU-mask) (accumulate)
 //
@@ -19,11 +21,35 @@
 // registers and is split/stored between the two barriers while the second half of the current tile's MFMAs runs.
 // Blocks are numbered so that the column blocks sharing one A row panel run back-to-back on ONE XCD (its L2 then
 // serves the re-reads; with the default order they land on 8 different L2s and A is fetched from HBM 2..8 times).
+//
+// fp16x2 (NT kernels).  x * s = hi + lo, both fp16 (round to nearest; hi + lo carries 22 significant bits), s the power of
+// two that puts the tensor's largest |x| into [2^14, 2^15).  The tensor maxima travel in "absmax slots" (common.h): the
+// weight's is reduced when its shadow is made, an activation's is committed by the kernel that PRODUCES it (encoder,
+// GEMM / LSTM / deconv epilogues: one atomic per wave) -- unreal_absmax_f32 is the stand-alone reduction for callers that
+// have none.  A product tile accumulates hh + hl + lh on v_mfma_f32_32x32x16_f16 (the dropped ll pair is < 2^-22 |ab|) and
+// is un-scaled exactly in the epilogue.  Gate (tools/exp/f16x2_gate.py, profiles/r03_f16x2_gate.log):
+// on the trainer's live operands at production shape the error against fp64 is BELOW the plain-fp32-MFMA kernel's
+// (rms and max) for fc forward, fc dgrad and the LSTM dgrad, at 1.3 - 1.7x the speed of the 6-pass kernel.  The wgrad
+// form first FAILED that gate at K = 81,920 (rms 4.6e-7 vs 2.3e-7; the 6-pass form it replaces: 1.5e-6): the MFMA's own
+// accumulation is biased over a 3,400-deep chain.  With the accumulators flushed into a second fp32 set every 8 K tiles
+// (SPLIT_TN_FLUSH) it passes (1.0e-7 / 2.9e-7 against 2.3e-7 / 6.6e-7) at 1.28x the speed of the shipped 6-pass kernel.
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;
+constexpr int MODE_BF16X3 = 0, MODE_F16X2 = 1;
+#ifndef SPLIT_NT_MODE
+#define SPLIT_NT_MODE 1     // 0: the round-2 bf16x3 NT kernels (A/B: tools/exp/f16x2_gate.py)
+#endif
+#ifndef SPLIT_TN_MODE
+#define SPLIT_TN_MODE 1     // 0: the round-2 bf16x3 wgrad kernel
+#endif
+__host__ __device__ constexpr int npl(int mode) { return mode == MODE_F16X2 ? 2 : 3; }   // operand planes
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int MODE> struct Frag { typedef __bf16 type __attribute__((ext_vector_type(8))); };
+template <> struct Frag<MODE_F16X2> { typedef f16x8 type; };
 constexpr int ROW_B = 80;                    // bytes per LDS row: 32 bf16 + 16 pad
 constexpr int FLAG_RELU = 1, FLAG_ACCUM = 2, FLAG_ATOMIC = 4, FLAG_RELU_MASK = 8, FLAG_RELU_BITS = 16;
 
@@ -66,6 +92,9 @@ struct SplitArgs {
   const float* A2; int lda2, K1, K1pad;
   // fused BPTT step (EPI == 2): the product is dh_rec of the EARLIER time step, whose gate backward runs in the epilogue
   const float* dh_above; float* dc_io; const float* gates_act; const float* c_new; float* dpre;     // c_prev: above
+  // fp16x2: absmax slots of A (max of the slot and a_floor) and of W (the one its shadow was made with); optional
+  // slots that receive max |output| (plain epilogue: C after bias / ReLU / mask; EPI == 2: dpre)
+  const float* a_absmax; float a_floor; const float* w_absmax; float* c_absmax0; float* c_absmax1;
 };
 
 // One 16-byte piece of the A tile per call (piece p of ROWS*BK/1024).  Branch-free on purpose: rows past the end
@@ -91,8 +120,17 @@ __device__ __forceinline__ f32x4 a_piece_load(const float* __restrict__ P, int l
 // PACKED selects how the residuals are subtracted: as 2-vectors (v_pk_add_f32) or with scalar v_sub_f32.  Same values
 // either way; A/B on one device: the NT kernels (one operand split) are 1-5 % faster with the scalar form, the TN
 // kernel (both operands split, twice the VALU) 5 % faster with the packed one.
-template <bool PACKED>
+template <bool PACKED, int MODE = MODE_BF16X3>
 __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float x3, u32x2 (&pl)[3]) {
+  if (MODE == MODE_F16X2) {   // x (already scaled) = hi + lo, both fp16, round to nearest; pl[2] unused
+    const f16x2 h01 = __builtin_convertvector((f32x2){x0, x1}, f16x2), h23 = __builtin_convertvector((f32x2){x2, x3}, f16x2);
+    const f32x2 r01 = (f32x2){x0, x1} - __builtin_convertvector(h01, f32x2), r23 = (f32x2){x2, x3} - __builtin_convertvector(h23, f32x2);
+    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+    pl[0] = (u32x2){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+    pl[1] = (u32x2){__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
+    pl[2] = pl[1];
+    return;
+  }
   if (PACKED) {
     f32x2 x01 = {x0, x1}, x23 = {x2, x3};
 #pragma unroll
@@ -119,16 +157,16 @@ __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float
 }
 
 // split 4 consecutive-k fp32 values into three bf16 planes and store 8 bytes per plane; klim = K - k0 of that tile
-template <int ROWS>
-__device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p, int tid) {
+template <int ROWS, int MODE>
+__device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p, int tid, float scale) {
   const int id = tid + 256 * p;
   const int r = row_deal(id / (BK / 4)), k = (id % (BK / 4)) * 4;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? v[e] : 0.f;
+  for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? (MODE == MODE_F16X2 ? v[e] * scale : v[e]) : 0.f;
   u32x2 pl[3];
-  split4_terms<false>(v[0], v[1], v[2], v[3], pl);
+  split4_terms<false, MODE>(v[0], v[1], v[2], v[3], pl);
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < npl(MODE); ++t)
     *reinterpret_cast<u32x2*>(S + (t * ROWS + r) * ROW_B + k * 2) = pl[t];
 }
 
@@ -150,23 +188,25 @@ __device__ __forceinline__ void w_piece_store(unsigned char* S, u32x4 v, int p, 
 }
 
 // SWZ: the 16-byte k chunk c of row r sits at chunk c ^ ((r >> 4) & 3) (transposing stores of the TN kernel)
-template <int BM, int BN, bool SWZ = false>
+template <int BM, int BN, int MODE, bool SWZ = false>
 __device__ __forceinline__ void read_frags(const unsigned char* As, const unsigned char* Bs, int wm, int wn, int li, int kh,
-                                           int ks, bf16x8 (&af)[BM / 64][3], bf16x8 (&bf)[BN / 64][3]) {
+                                           int ks, typename Frag<MODE>::type (&af)[BM / 64][npl(MODE)],
+                                           typename Frag<MODE>::type (&bf)[BN / 64][npl(MODE)]) {
+  typedef typename Frag<MODE>::type frag8;
   const int c = 2 * ks + kh;
 #pragma unroll
   for (int i = 0; i < BM / 64; ++i)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < npl(MODE); ++t) {
       const int r = wm * (BM / 2) + i * 32 + li;
-      af[i][t] = *reinterpret_cast<const bf16x8*>(As + (t * BM + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
+      af[i][t] = *reinterpret_cast<const frag8*>(As + (t * BM + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
     }
 #pragma unroll
   for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < npl(MODE); ++t) {
       const int r = wn * (BN / 2) + j * 32 + li;
-      bf[j][t] = *reinterpret_cast<const bf16x8*>(Bs + (t * BN + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
+      bf[j][t] = *reinterpret_cast<const frag8*>(Bs + (t * BN + r) * ROW_B + (SWZ ? (c ^ ((r >> 4) & 3)) : c) * 16);
     }
 }
 
@@ -183,6 +223,20 @@ __device__ __forceinline__ void mma_frags(const bf16x8 (&af)[TM][3], const bf16x
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_frags(const f16x8 (&af)[TM][2], const f16x8 (&bf)[TN][2], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f32x16 c = acc[i][j];
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], c, 0, 0, 0);    // lo * hi, hi * lo, hi * hi
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], c, 0, 0, 0);
       acc[i][j] = c;
     }
 }
@@ -232,9 +286,18 @@ __device__ __forceinline__ ASrc<DUAL> a_src(const SplitArgs& p, int kg) {
 
 template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false>
 __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kernel(SplitArgs p) {
+  constexpr int MODE = SPLIT_NT_MODE, NPL = npl(MODE);
+  typedef typename Frag<MODE>::type frag8;
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int PA = BM * BK / 1024, PW = 3 * BN / 64;
-  constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
+  constexpr int PA = BM * BK / 1024, PW = NPL * BN / 64;
+  constexpr int A_BYTES = NPL * BM * ROW_B, B_BYTES = NPL * BN * ROW_B;
+  // fp16x2: the tensors' power-of-two scales (exact), read once; everything below is scale-free in the bf16x3 mode
+  float SA = 1.f, INV_A = 1.f, INV_W = 1.f;
+  if (MODE == MODE_F16X2) {
+    SA = pow2_scale(fmaxf(p.a_absmax ? *p.a_absmax : 0.f, p.a_floor));
+    INV_A = pow2_inv(SA);
+    INV_W = pow2_inv(pow2_scale(*p.w_absmax));
+  }
   constexpr int C_BYTES = BM * (BN + 4) * 4;
   constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[KW * SMEM];
@@ -286,7 +349,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
 #pragma unroll
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q, tid);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) a_piece_store<BM>(As, ra[0][q], KLIM(0, s0), q, tid);
+    for (int q = 0; q < PA; ++q) a_piece_store<BM, MODE>(As, ra[0][q], KLIM(0, s0), q, tid, SA);
 #pragma unroll
     for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q, tid);
     const int k1 = KG_AT(1), k2 = KG_AT(2);
@@ -312,18 +375,18 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
   // interleaves it (explicit sched_group_barrier pipelines measured 5-10 % slower than its own schedule).
 #define SPLIT_NT_TILE(S, IT)                                                                                        \
   {                                                                                                                 \
-    bf16x8 af[TM][3], bf[TN][3];                                                                                    \
+    frag8 af[TM][NPL], bf[TN][NPL];                                                                                  \
     if (!(SPLIT_ABLATE & 4)) {                                                                                      \
-      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 0, af, bf);                                                        \
+      read_frags<BM, BN, MODE>(As, Bs, wm, wn, li, kh, 0, af, bf);                                                  \
       mma_frags<TM, TN>(af, bf, acc);                                                                               \
-      read_frags<BM, BN>(As, Bs, wm, wn, li, kh, 1, af, bf);   /* second half: read before, multiplied after */     \
+      read_frags<BM, BN, MODE>(As, Bs, wm, wn, li, kh, 1, af, bf);   /* second half: read before, multiplied after */ \
     }                                                                                                               \
     __syncthreads();                                   /* every wave has read tile IT */                            \
     const int kcur = KG_AT((IT) + 1), kw = KG_AT((IT) + 2), ka = KG_AT((IT) + (DEEP ? 3 : 2));                      \
     const ASrc<DUAL> scur = a_src<DUAL>(p, kcur), snext = a_src<DUAL>(p, ka);                                       \
     const int klim = KLIM((IT) + 1, scur);                                                                          \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
-      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM>(As, ra[S][q], klim, q, tid);                          \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM, MODE>(As, ra[S][q], klim, q, tid, SA);                \
       if (!(SPLIT_ABLATE & 1)) ra[S][q] = A_LOAD(snext, q);                                                         \
     }                                                                                                               \
     _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
@@ -360,7 +423,8 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r] + bv);
+          const float v = MODE == MODE_F16X2 ? (acc[i][j][r] * INV_A) * INV_W : acc[i][j][r];
+          if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, v + bv);
         }
       }
     return;
@@ -375,7 +439,8 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
+        Cs[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] =
+            MODE == MODE_F16X2 ? (acc[i][j][r] * INV_A) * INV_W : acc[i][j][r];
   __syncthreads();
   SSTAMP(2);       // partial tiles parked in LDS
   const float* C0 = reinterpret_cast<const float*>(smem_all);
@@ -436,6 +501,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     // for 64 hidden units u; with it the gate backward of step t-1 is purely element-wise -- same arithmetic, in the same
     // order, as unreal_lstm_gates_bwd after the stand-alone product, so the two paths agree bit for bit.
     constexpr int ITEMS = BM * BN / (256 * KW), CH = ITEMS < 4 ? ITEMS : 4;
+    float omax = 0.f;
 #pragma unroll
     for (int e0 = 0; e0 < ITEMS; e0 += CH) {
       float dha[CH], dcv[CH], cn[CH], cp[CH], ga[CH][4];
@@ -461,13 +527,15 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         const float tc = tanhf(cn[e]);
         const float dc = dcv[e] + dh * o * (1.f - tc * tc);
         float* d = p.dpre + (g / 256) * 1024 + g % 256;
-        d[0] = dc * j * i * (1.f - i);
-        d[256] = dc * i * (1.f - j * j);
-        d[512] = dc * cp[e] * f * (1.f - f);
-        d[768] = dh * tc * o * (1.f - o);
+        const float d0 = dc * j * i * (1.f - i), d1 = dc * i * (1.f - j * j), d2 = dc * cp[e] * f * (1.f - f),
+                    d3 = dh * tc * o * (1.f - o);
+        d[0] = d0; d[256] = d1; d[512] = d2; d[768] = d3;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
         p.dc_io[g] = dc * f;
       }
     }
+    absmax_commit(p.c_absmax0, omax);       // max |d_gates| of the step just produced: the next step's A scale
+    absmax_commit(p.c_absmax1, omax);
     return;
   }
   // FLAG_RELU_BITS: mask is a bit matrix (uint16 words, row stride ldm words, bit j % 16 of word j / 16 = column j kept)
@@ -476,6 +544,8 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
                     (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
                     (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
   constexpr int CV = BN / 4;
+  float omax = 0.f;
+  static_assert((BM * CV) % (256 * KW) == 0, "every lane makes the same number of passes (absmax_commit needs whole waves)");
   for (int id = threadIdx.x; id < BM * CV; id += 256 * KW) {
     const int r = id / CV, c4 = (id % CV) * 4;
     const int row = m0 + r, col = n0 + c4;
@@ -502,6 +572,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? v[e] : 0.f;
       }
       *reinterpret_cast<f32x4*>(cp) = v;
+      omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -512,9 +583,11 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         if (p.flags & FLAG_RELU_MASK) x = (p.mask[(size_t)row * p.ldm + col + e] > 0.f) ? x : 0.f;
         if (p.flags & FLAG_RELU_BITS) x = ((mbits[(size_t)row * p.ldm + ((col + e) >> 4)] >> ((col + e) & 15)) & 1u) ? x : 0.f;
         cp[e] = x;
+        omax = fmaxf(omax, fabsf(x));
       }
     }
   }
+  if (p.c_absmax0) absmax_commit(p.c_absmax0, omax);    // (block-uniform pointer; every lane left the loop together)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -532,6 +605,7 @@ struct SplitTnArgs {
   float* C; int ldc;
   float* colsum;                       // nullable: colsum[n] += sum_k B[k][n] (the bias gradient that goes with dW)
   int ntx, nty, splitk, ktiles_per_split;
+  const float* a_absmax; const float* b_absmax;     // fp16x2: absmax slots of A and B
 };
 
 // Thread -> (m4: which 4 columns of the 128, k4: which 4 k rows of the 32) of the TN tile it stages.  Lane order
@@ -562,8 +636,8 @@ __device__ __forceinline__ void tn_piece_load(const float* __restrict__ P, int l
   }
 }
 
-template <int ROWS>
-__device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&reg)[4], int klim) {
+template <int ROWS, int MODE>
+__device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&reg)[4], int klim, float scale) {
   const int m4 = tn_m4(), k4 = tn_k4();
   bool ok[4];
 #pragma unroll
@@ -572,10 +646,12 @@ __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&r
   for (int j = 0; j < 4; ++j) {
     const int r = 4 * m4 + j;
     u32x2 pl[3];
-    split4_terms<true>(ok[0] ? reg[0][j] : 0.f, ok[1] ? reg[1][j] : 0.f, ok[2] ? reg[2][j] : 0.f, ok[3] ? reg[3][j] : 0.f, pl);
+    const float sc = MODE == MODE_F16X2 ? scale : 1.f;
+    split4_terms<true, MODE>(ok[0] ? reg[0][j] * sc : 0.f, ok[1] ? reg[1][j] * sc : 0.f, ok[2] ? reg[2][j] * sc : 0.f,
+                             ok[3] ? reg[3][j] * sc : 0.f, pl);
     const int off = (((k4 >> 1) ^ ((r >> 4) & 3)) * 2 + (k4 & 1)) * 8;       // swizzled 16-B chunk, 8-B half
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < npl(MODE); ++t)
       *reinterpret_cast<u32x2*>(S + (t * ROWS + r) * ROW_B + off) = pl[t];
   }
 }
@@ -593,8 +669,15 @@ __device__ __forceinline__ void tn_colsum_acc(const f32x4 (&reg)[4], int klim, f
 
 __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  constexpr int A_BYTES = 3 * BM * ROW_B, B_BYTES = 3 * BN * ROW_B;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES];
+  constexpr int MODE = SPLIT_TN_MODE, NPL = npl(MODE);
+  typedef typename Frag<MODE>::type frag8;
+  constexpr int A_BYTES = NPL * BM * ROW_B, B_BYTES = NPL * BN * ROW_B;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES > 8 * BN * 4 ? A_BYTES + B_BYTES : 8 * BN * 4];
+  float SA = 1.f, SB = 1.f, INV_A = 1.f, INV_B = 1.f;
+  if (MODE == MODE_F16X2) {
+    SA = pow2_scale(*p.a_absmax); SB = pow2_scale(*p.b_absmax);
+    INV_A = pow2_inv(SA); INV_B = pow2_inv(SB);
+  }
   unsigned char* As = smem;
   unsigned char* Bs = smem + A_BYTES;
 
@@ -622,6 +705,22 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifndef SPLIT_TN_FLUSH
+#define SPLIT_TN_FLUSH 8      // K tiles between two flushes of the MFMA accumulators (0: never)
+#endif
+  // Long-K accuracy: the MFMA adds its 16 products into the running accumulator with a rounding that is biased (measured:
+  // at K = 81,920 the error of a 3,400-long chain grows linearly with the chain, fp16x2 4.6e-7 and bf16x3 1.5e-6 rms against
+  // 2.3e-7 for the fp32 MFMA's round-to-nearest chain).  So every SPLIT_TN_FLUSH tiles the accumulators are added into a
+  // second fp32 set with ordinary VALU adds (round to nearest) and restarted from zero: the MFMA chains stay short.
+  f32x16 tot[TM][TN];
+  if (SPLIT_TN_FLUSH > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  }
   f32x4 ra[4], rb[4];
   // bias gradient: the row of tiles by == 0 also sums the columns of every B tile it stages (multiplying by 0
   // elsewhere keeps the K loop one basic block)
@@ -629,8 +728,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   tn_piece_load(p.A, p.lda, p.K, m0, kt0 * BK, ra);
   tn_piece_load(p.B, p.ldb, p.K, n0, kt0 * BK, rb);
-  tn_piece_store<BM>(As, ra, p.K - kt0 * BK);
-  tn_piece_store<BN>(Bs, rb, p.K - kt0 * BK);
+  tn_piece_store<BM, MODE>(As, ra, p.K - kt0 * BK, SA);
+  tn_piece_store<BN, MODE>(Bs, rb, p.K - kt0 * BK, SB);
   tn_colsum_acc(rb, p.K - kt0 * BK, csw, cs);
   {
     const int k1 = (kt0 + min(1, nkt - 1)) * BK;
@@ -640,20 +739,36 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   __syncthreads();
 
   for (int it = 0; it < nkt; ++it) {
-    bf16x8 af[TM][3], bf[TN][3];
-    read_frags<BM, BN, true>(As, Bs, wm, wn, li, kh, 0, af, bf);
+    frag8 af[TM][NPL], bf[TN][NPL];
+    read_frags<BM, BN, MODE, true>(As, Bs, wm, wn, li, kh, 0, af, bf);
     mma_frags<TM, TN>(af, bf, acc);
-    read_frags<BM, BN, true>(As, Bs, wm, wn, li, kh, 1, af, bf);
+    read_frags<BM, BN, MODE, true>(As, Bs, wm, wn, li, kh, 1, af, bf);
     __syncthreads();                                   // every wave has read tile `it`
     // unconditional like the NT kernel: one basic block, the compiler interleaves split VALU, loads and MFMAs
     const int kcur = (kt0 + min(it + 1, nkt - 1)) * BK, knext = (kt0 + min(it + 2, nkt - 1)) * BK;
-    tn_piece_store<BM>(As, ra, p.K - kcur);
+    tn_piece_store<BM, MODE>(As, ra, p.K - kcur, SA);
     tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
-    tn_piece_store<BN>(Bs, rb, p.K - kcur);
+    tn_piece_store<BN, MODE>(Bs, rb, p.K - kcur, SB);
     tn_colsum_acc(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);      // the last pass re-stages a tile already counted
     tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
     mma_frags<TM, TN>(af, bf, acc);
+    if (SPLIT_TN_FLUSH > 0 && (it + 1) % SPLIT_TN_FLUSH == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+    }
     __syncthreads();                                   // tile `it + 1` is visible
+  }
+  if (SPLIT_TN_FLUSH > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
   }
 
   if (csw != 0.f) {      // block-uniform; the K loop ended with a barrier, so the operand LDS is free
@@ -679,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, acc[i][j][r]);
+        if (row < p.M) atomicAdd(p.C + (size_t)row * p.ldc + col, MODE == MODE_F16X2 ? (acc[i][j][r] * INV_A) * INV_B : acc[i][j][r]);
       }
     }
 }
@@ -711,14 +826,78 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int rows, int cols, c
   }
 }
 
+// weights -> fp16x2 planes (hi, lo of src * 2^k, k from the weight's absmax slot): same tiling / layouts as above
+__global__ __launch_bounds__(256) void split_planes_f16x2_kernel(int rows, int cols, const float* __restrict__ src, int ld_src,
+                                                                 int transpose, unsigned short* __restrict__ dst, int ld_dst,
+                                                                 long plane, int row_perm, const float* __restrict__ w_absmax) {
+  __shared__ float t[32][33];
+  const float sw = pow2_scale(*w_absmax);
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int y = ty; y < 32; y += 8)
+    if (r0 + y < rows && c0 + tx < cols) t[y][tx] = src[(size_t)(r0 + y) * ld_src + c0 + tx];
+  __syncthreads();
+  for (int y = ty; y < 32; y += 8) {
+    int orow = transpose ? c0 + y : r0 + y;
+    const int ocol = transpose ? r0 + tx : c0 + tx;
+    if (row_perm == 1) orow = ((orow & 255) >> 4) * 64 + (orow >> 8) * 16 + (orow & 15);   // LSTM gate interleave
+    const bool ok = transpose ? (c0 + y < cols && r0 + tx < rows) : (r0 + y < rows && c0 + tx < cols);
+    if (!ok) continue;
+    const float x = (transpose ? t[tx][y] : t[y][tx]) * sw;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    dst[(size_t)orow * ld_dst + ocol] = __builtin_bit_cast(unsigned short, h);
+    dst[plane + (size_t)orow * ld_dst + ocol] = __builtin_bit_cast(unsigned short, l);
+  }
+}
+
+// slot = max(slot, max |x[r][c]|): the stand-alone reduction for tensors whose producer does not commit its own maximum
+__global__ __launch_bounds__(256) void absmax_kernel(int rows, int cols, const float* __restrict__ x, int ld, float* slot) {
+  float m = 0.f;
+  if (ld == cols && (cols & 3) == 0 && ((((uintptr_t)x) & 15) == 0)) {      // contiguous: 16 bytes per lane
+    const long n4 = (long)rows * cols / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      const f32x4 v = x4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  } else {                                     // a column window of a wider matrix: one row per wave at a time
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < rows; r += nw)
+      for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[(size_t)r * ld + c]));
+  }
+  absmax_commit(slot, m);
+}
+
 }  // namespace
 
 extern "C" {
 
-int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const uint16_t* W3, int ldw, long plane_stride,
-                             float* C, int ldc, const float* bias, const void* mask, int ldm, int flags, int splitk,
-                             void* stream) {
+int unreal_absmax_f32(int rows, int cols, const float* x, int ld, float* slot, void* stream) {
+  if (rows <= 0 || cols <= 0 || !x || !slot || ld < cols) return UNREAL_EINVAL;
+  const long n = (long)rows * cols;
+  const int grid = (int)min((n + 1023) / 1024, 512L);
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows, cols, x, ld, slot);
+  return unreal_launch_status();
+}
+
+int unreal_split_f16x2(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
+                       int ld_dst, long plane_stride, const float* w_absmax, void* stream) {
+  if (rows <= 0 || cols <= 0 || !src || !dst || ld_src < cols || !w_absmax) return UNREAL_EINVAL;
+  const int orows = transpose ? cols : rows, ocols = transpose ? rows : cols;
+  if (ld_dst < ocols || plane_stride < (long)orows * ld_dst) return UNREAL_EINVAL;
+  if (row_perm != 0 && (row_perm != 1 || orows != 1024)) return UNREAL_EINVAL;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(split_planes_f16x2_kernel, grid, dim3(256), 0, (hipStream_t)stream, rows, cols, src, ld_src, transpose,
+                     dst, ld_dst, plane_stride, row_perm, w_absmax);
+  return unreal_launch_status();
+}
+
+int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3, int ldw,
+                             long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax, const float* bias,
+                             const void* mask, int ldm, int flags, int splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W3 || !C) return UNREAL_EINVAL;
+  if (SPLIT_NT_MODE == MODE_F16X2 && (!a_absmax || !w_absmax)) return UNREAL_EINVAL;
   const int kpad = (K + BK - 1) / BK * BK;
   if (lda < K || ldw < kpad || (ldw & 7) || (plane_stride & 7) || plane_stride < (long)N * ldw || ldc < N ||
       (((uintptr_t)W3) & 15))
@@ -737,6 +916,8 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.K1pad = 0;
   a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
+  a.a_absmax = a_absmax; a.a_floor = 0.f; a.w_absmax = w_absmax; a.c_absmax0 = (flags & FLAG_ATOMIC) ? nullptr : c_absmax;
+  a.c_absmax1 = nullptr;
   {
     const int nk = (K + BK - 1) / BK;
     if (splitk > nk) splitk = nk;
@@ -764,10 +945,11 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   return unreal_launch_status();
 }
 
-int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* h_prev, int ld_hprev, const uint16_t* W3,
-                         int ldw, long plane_stride, float* gates, const float* bias, const float* c_prev, float* c_out,
-                         float* h_out, int ld_h, void* stream) {
+int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* x_absmax, const float* h_prev, int ld_hprev,
+                         const uint16_t* W3, int ldw, long plane_stride, const float* w_absmax, float* gates, const float* bias,
+                         const float* c_prev, float* c_out, float* h_out, int ld_h, void* stream) {
   if (rows <= 0 || !h_prev || !W3 || !gates || !bias || !c_prev || !c_out || !h_out) return UNREAL_EINVAL;
+  if (SPLIT_NT_MODE == MODE_F16X2 && (!w_absmax || (x && !x_absmax))) return UNREAL_EINVAL;
   const int kxpad = x ? (Kx + BK - 1) / BK * BK : 0;
   if (x && (Kx <= 0 || ldx < Kx)) return UNREAL_EINVAL;
   if (ld_hprev < 256 || ld_h < 256 || ldw < kxpad + 256 || (ldw & 7) || (plane_stride & 7) ||
@@ -779,6 +961,8 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
   a.bias = bias; a.mask = nullptr; a.ldm = 0;
   a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.ld_h = ld_h;
   a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
+  // A = [x | h_prev]: |h| < 1 by construction (tanh * sigmoid), so the scale covers max(1, max |x|)
+  a.a_absmax = x ? x_absmax : nullptr; a.a_floor = 1.f; a.w_absmax = w_absmax; a.c_absmax0 = nullptr; a.c_absmax1 = nullptr;
   a.splitk = 1; a.ktiles_per_split = a.K / BK;
   a.nbx = 16; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
@@ -817,10 +1001,12 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
   return unreal_launch_status();
 }
 
-int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, int ldw, long plane_stride,
-                          const float* dh_above, float* dc_io, const float* gates_act, const float* c_prev,
-                          const float* c_new, float* dpre, void* stream) {
+int unreal_lstm_bptt_step(int rows, const float* d_gates, const float* a_absmax, const uint16_t* Wh3, int ldw, long plane_stride,
+                          const float* w_absmax, const float* dh_above, float* dc_io, const float* gates_act,
+                          const float* c_prev, const float* c_new, float* dpre, float* dpre_absmax0, float* dpre_absmax1,
+                          void* stream) {
   if (rows <= 0 || !d_gates || !Wh3 || !dh_above || !dc_io || !gates_act || !c_prev || !c_new || !dpre) return UNREAL_EINVAL;
+  if (SPLIT_NT_MODE == MODE_F16X2 && (!a_absmax || !w_absmax)) return UNREAL_EINVAL;
   if (ldw < 1024 || (ldw & 7) || (plane_stride & 7) || plane_stride < 256L * ldw || (((uintptr_t)Wh3) & 15) ||
       (((uintptr_t)d_gates) & 15))
     return UNREAL_EINVAL;
@@ -831,6 +1017,7 @@ int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, i
   a.c_prev = c_prev; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   a.A2 = nullptr; a.lda2 = 0; a.K1 = 1024; a.K1pad = 0;
   a.dh_above = dh_above; a.dc_io = dc_io; a.gates_act = gates_act; a.c_new = c_new; a.dpre = dpre;
+  a.a_absmax = a_absmax; a.a_floor = 0.f; a.w_absmax = w_absmax; a.c_absmax0 = dpre_absmax0; a.c_absmax1 = dpre_absmax1;
   a.splitk = 1; a.ktiles_per_split = 1024 / BK;
   a.nbx = 4; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
@@ -846,12 +1033,14 @@ int unreal_lstm_bptt_step(int rows, const float* d_gates, const uint16_t* Wh3, i
   return unreal_launch_status();
 }
 
-int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                             float* colsum, int splitk, void* stream) {
+int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const float* a_absmax, const float* B, int ldb,
+                             const float* b_absmax, float* C, int ldc, float* colsum, int splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C || lda < M || ldb < N || ldc < N) return UNREAL_EINVAL;
   if ((lda & 3) || (ldb & 3) || lda < 4 || ldb < 4 || (((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return UNREAL_EINVAL;
   SplitTnArgs a;
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.colsum = colsum;
+  a.a_absmax = a_absmax; a.b_absmax = b_absmax;
+  if (SPLIT_TN_MODE == MODE_F16X2 && (!a.a_absmax || !a.b_absmax)) return UNREAL_EINVAL;
   a.ntx = (N + 127) / 128; a.nty = (M + 127) / 128;
   const int nk = (K + BK - 1) / BK;
   if (splitk < 1) splitk = 1;

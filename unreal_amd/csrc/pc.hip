@@ -300,6 +300,7 @@ struct PcBwdArgs {
   const float* Wv; const float* Wa;
   float* d_hp;              // [N][2592] gradient wrt pc_fc1 PRE-activation (relu mask applied)
   float* dWv; float* dbv; float* dWa; float* dba;
+  float* dhp_absmax;        // nullable absmax slot (common.h): max |d_hp|, the A scale of the pc_fc1 dgrad GEMM
 };
 
 // Backward on the split-operand scheme of the forward (three bf16 planes per operand, six term-pair MFMAs):
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) adbk[k] = 0.f;
   (void)adb;
+  float dhp_max = 0.f;     // max |d_hp| this thread has stored
   const int nt = gw & 1;
   const int qq = i >> 2, pp = i & 3;             // transposed reads: lane (4qq + pp) of a 16-lane group addresses block row qq
 
@@ -504,7 +506,11 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     __syncthreads();  // [S1] all reads of the planes done; dhs of frame n complete
     if (valid) {      // d_hp leaves in full 128 B lines
       f32x4* dst = reinterpret_cast<f32x4*>(p.d_hp + (size_t)n * F2_DIM);
-      for (int id = gtid; id < F2_DIM / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dhs)[id];
+      for (int id = gtid; id < F2_DIM / 4; id += 256) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(dhs)[id];
+        dst[id] = v;
+        dhp_max = fmaxf(fmaxf(dhp_max, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
     }
     if (has_next) {
       hp_store_planes(hpp, gtid, pre_hp);
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       else atomicAdd(p.dba + (k - 1), v);
     }
   }
+  absmax_commit(p.dhp_absmax, dhp_max);
 }
 
 }  // namespace
@@ -552,11 +559,11 @@ int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const f
 }
 
 int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, const float* Wv, const float* Wa,
-                         float* d_hp, float* dWv, float* dbv, float* dWa, float* dba, void* stream) {
+                         float* d_hp, float* dhp_absmax, float* dWv, float* dbv, float* dWa, float* dba, void* stream) {
   if (N <= 0 || A <= 0 || A > 7 || !hp || !d_dec || !Wv || !Wa || !d_hp || !dWv || !dbv || !dWa || !dba)
     return UNREAL_EINVAL;
   if ((((uintptr_t)hp) | ((uintptr_t)d_dec) | ((uintptr_t)d_hp)) & 15) return UNREAL_EINVAL;
-  PcBwdArgs p{N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba};
+  PcBwdArgs p{N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_absmax};
   int blocks = min(N, 512);
   hipLaunchKernelGGL(pc_deconv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();

@@ -44,6 +44,7 @@ class Evaluate(object):
         if one_episode_per_actor:
             n_episodes = B
         while done < n_episodes:
+            net.begin_pass()
             ring.cur_idx(out=ws.frame_idx[:B])
             net.encode_rows(ring, ws, 0, B, lar_from_ring=False, save_c1=False, lstm_x=False)
             if net._use_lstm:

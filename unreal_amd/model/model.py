@@ -89,6 +89,8 @@ class PathWS(object):
     def __init__(self, rows, B, device, save_c1=True, lstm=True, xld=XLD):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
         self.rows, self.B, self.xld = rows, B, xld
+        self.s_x = self.s_f2 = self.s_x_cur = None     # absmax slots of the rows' LSTM input x / conv output (UnrealModel.encode_rows, per pass)
+        self.pass_id = None
         self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
         self.c1 = f(rows * ops.C1_DIM) if save_c1 else None
         self.f2 = f(rows * ops.F2_DIM)
@@ -196,6 +198,13 @@ class UnrealModel(object):
         self._b1 = None
         self._shadow = None
         self._shadow_stale = True
+        # absmax slots (fp16x2 GEMM scales, csrc/gemm_split.hip): a pool zeroed once per pass; a constant 1.0 for tensors
+        # bounded by 1 (LSTM outputs); lar_bounded: [last action one-hot | last reward] stays within 1 (maze rewards are
+        # -1 / 0 / +1, the Lab contract clips) -- Trainer clears it for environments that feed raw rewards
+        self.slots = ops.AbsmaxPool(self._device)
+        self.pass_id = 0
+        self._one = torch.ones(1, dtype=torch.float32, device=self._device)
+        self.lar_bounded = True
 
     def bind_frame_scale(self, scale):
         """Adopt the byte scale of the environment whose ring this network reads (raises if the caller fixed another)."""
@@ -290,6 +299,15 @@ class UnrealModel(object):
         self.base_lstm_state_out = (z, z.clone())     # (c, h) like LSTMStateTuple
 
     # -- batched building blocks -----------------------------------------------------------------------
+    def new_slot(self):
+        """An absmax slot of the current pass (ops.AbsmaxPool; Trainer / Evaluate / the batch-1 runners call
+        begin_pass() once per pass: the pool is zeroed with one fill)."""
+        return self.slots.new()
+
+    def begin_pass(self):
+        self.slots.reset()
+        self.pass_id += 1
+
     def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
                     objective_slot_offset=0, actor_ring=None, lar_prefilled=False, lstm_x=True):
         """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
@@ -302,12 +320,27 @@ class UnrealModel(object):
         xcat = ws.xcat[row0 * self.xld:]
         c1 = ws.c1[row0 * ops.C1_DIM:] if (save_c1 and ws.c1 is not None) else None
         bits = ws.f2_bits[row0 * ops.RELU_WORDS:] if (c1 is not None and ws.f2_bits is not None) else None
+        # absmax slots: the encoder commits max f2, the fc GEMM reads it and commits max of its own output -- the scale of
+        # the product that multiplies the fc row next (LSTM step: [fc | last action, reward, objective | h])
+        # The slots belong to the WORKSPACE for the pass: a rollout encodes its rows block by block, the wgrad products of
+        # the backward read all of them, so every block maxes into the same two slots (a block's own products then use the
+        # running maximum: >= its rows', deterministic because the launches are stream-ordered).  Blocks encoded on
+        # separate streams (host-fed half-batches, `actor_ring`) take fresh slots and merge them into the workspace's.
+        if getattr(ws, "pass_id", None) != self.pass_id:
+            ws.s_f2, ws.s_x, ws.pass_id = self.new_slot(), self.new_slot(), self.pass_id
+        own = actor_ring is not None
+        s_f2, s_fc = (self.new_slot(), self.new_slot()) if own else (ws.s_f2, ws.s_x)
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
-                        p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits)
+                        p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2)
         sh = self.shadow
         ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
-                          flags=ops.GEMM_RELU)
+                          flags=ops.GEMM_RELU, a_max=s_f2, c_max=s_fc)
+        ws.s_x_cur = s_fc          # max over the fc columns; the other columns of x are added below where they can exceed 1
+        if own:
+            ops.absmax(1, 1, s_f2, 1, ws.s_f2)
         if not self._use_lstm:
+            if own:
+                ops.absmax(1, 1, s_fc, 1, ws.s_x)
             return
         A = self._action_size
         if lar_prefilled:
@@ -319,8 +352,15 @@ class UnrealModel(object):
             ops.lar_fill(nrows, A, ar.last_action, ar.last_reward, None, xcat, self.xld, clip=clip_lar)
         if self._objective_size:
             ops.objective_fill(ring, nrows, idx, xcat, self.xld, 256 + A + 1, slot_offset=objective_slot_offset)
+        # [one-hot last action | last reward | objective]: the one-hot and a clipped reward stay within the kernel's own
+        # floor of 1 (|h| < 1); raw rewards / measurement vectors (host-fed actors) are reduced into the slot
+        if self._objective_size or not self.lar_bounded:
+            ops.absmax(nrows, self.K_x - 256, xcat[256:], self.xld, s_fc)
+        if own:
+            ops.absmax(1, 1, s_fc, 1, ws.s_x)
         if lstm_x:
-            ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024)
+            ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024,
+                              a_max=ops.absmax(nrows, self.K_x, xcat, self.xld, self.new_slot()))
 
     def lstm_step(self, ws, t, B, b0=0, nrows=None, fused_x=False):
         """One BasicLSTMCell step for time row-block t; `b0`, `nrows`: only the actors [b0, b0 + nrows) of the block.
@@ -334,7 +374,7 @@ class UnrealModel(object):
         if fused_x:
             ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_xh_fwd"], g_t, p["lstm_bias"], c_prev,
                               ws.c[(t * B + b0) * 256:], ws.h[(t * B + b0) * 256:],
-                              x=ws.xcat[(t * B + b0) * self.xld:], ldx=self.xld, Kx=self.K_x)
+                              x=ws.xcat[(t * B + b0) * self.xld:], ldx=self.xld, Kx=self.K_x, x_max=ws.s_x_cur)
             return
         ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[(t * B + b0) * 256:],
                           ws.h[(t * B + b0) * 256:])
@@ -373,29 +413,39 @@ class UnrealModel(object):
             W = p["lstm_kernel"]
             Wh = W[K_x * 1024:]
             gws.dc.zero_()
+            # absmax slots of d_gates: one per time step (the A scale of the step's recurrent product) and one over the
+            # whole sequence (the A scale of the fc dgrad below); the gate-backward epilogues commit into both
+            s_all = self.new_slot()
+            s_step = self.new_slot()
             if self.fuse_bptt:
                 # the last step's gate backward stands alone; every earlier step's runs in the epilogue of the product
                 # that yields its dh_rec (one launch per step instead of two, dh_rec never written)
                 c_prev = ws.c0 if T == 1 else ws.c[(T - 2) * B * 256:]
                 ops.lstm_gates_bwd(B, d_feat[(T - 1) * B * 256:], None, gws.dc, ws.gates[(T - 1) * B * 1024:], c_prev,
-                                   ws.c[(T - 1) * B * 256:], gws.d_gates[(T - 1) * B * 1024:])
+                                   ws.c[(T - 1) * B * 256:], gws.d_gates[(T - 1) * B * 1024:], c_max0=s_step, c_max1=s_all)
                 for t in reversed(range(1, T)):
                     c_prev = ws.c0 if t == 1 else ws.c[(t - 2) * B * 256:]
+                    s_next = self.new_slot()
                     ops.lstm_bptt_step(B, gws.d_gates[t * B * 1024:], sh["lstm_h_dgrad"], d_feat[(t - 1) * B * 256:],
                                        gws.dc, ws.gates[(t - 1) * B * 1024:], c_prev, ws.c[(t - 1) * B * 256:],
-                                       gws.d_gates[(t - 1) * B * 1024:])
+                                       gws.d_gates[(t - 1) * B * 1024:], a_max=s_step, c_max0=s_next, c_max1=s_all)
+                    s_step = s_next
             else:                                      # the two-kernel form (bit-identical; kept for A/B timing)
                 for t in reversed(range(T)):
                     c_prev = ws.c0 if t == 0 else ws.c[(t - 1) * B * 256:]
+                    s_step = self.new_slot()
                     ops.lstm_gates_bwd(B, d_feat[t * B * 256:], gws.dh_rec if t < T - 1 else None, gws.dc,
-                                       ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:], gws.d_gates[t * B * 1024:])
+                                       ws.gates[t * B * 1024:], c_prev, ws.c[t * B * 256:], gws.d_gates[t * B * 1024:],
+                                       c_max0=s_step, c_max1=s_all)
                     if t > 0:
-                        ops.gemm_split_nt(B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, sh["lstm_h_dgrad"], gws.dh_rec, 256)
+                        ops.gemm_split_nt(B, 256, 1024, gws.d_gates[t * B * 1024:], 1024, sh["lstm_h_dgrad"], gws.dh_rec, 256,
+                                          a_max=s_step)
             dW = g["lstm_kernel"]
             # input half of the kernel gradient: the 256 fc rows as two exact 128-row MFMA tiles, the A+1
             # last_action_reward rows by the small-N outer-product kernel (no padded third tile)
             ops.gemm_split_tn(256, 1024, rows, ws.xcat, self.xld, gws.d_gates, 1024, dW, 1024,
-                              splitk=_splitk(256, 1024, rows), colsum=g["lstm_bias"])     # + bias gradient
+                              splitk=_splitk(256, 1024, rows), colsum=g["lstm_bias"],     # + bias gradient
+                              a_max=ws.s_x, b_max=s_all)
             c0 = 256
             for w in _small_chunks(K_x - 256):         # last action, last reward (and objective) rows
                 ops.linear_small_bwd(rows, 1024, w, gws.d_gates, 1024, ws.xcat[c0:], self.xld, None, None, 0, False,
@@ -404,24 +454,26 @@ class UnrealModel(object):
             if T > 1:
                 r1 = (T - 1) * B
                 ops.gemm_split_tn(256, 1024, r1, ws.h, 256, gws.d_gates[B * 1024:], 1024, dW[K_x * 1024:], 1024,
-                              splitk=_splitk(256, 1024, r1))
+                              splitk=_splitk(256, 1024, r1), a_max=self._one, b_max=s_all)      # |h| < 1
             if h0_nonzero:
                 ops.gemm_split_tn(256, 1024, B, ws.h0, 256, gws.d_gates, 1024, dW[K_x * 1024:], 1024,
-                              splitk=_splitk(256, 1024, B))
+                              splitk=_splitk(256, 1024, B), a_max=self._one, b_max=s_all)
+            s_dfc = self.new_slot()
             ops.gemm_split_nt(rows, 256, 1024, gws.d_gates, 1024, sh["lstm_fc_dgrad"], gws.d_fc, 256, mask=ws.xcat,
-                              ldm=self.xld, flags=ops.GEMM_RELU_MASK)
+                              ldm=self.xld, flags=ops.GEMM_RELU_MASK, a_max=s_all, c_max=s_dfc)
             d_fc = gws.d_fc
         else:
             ops.relu_mask(rows, 256, d_feat, 256, ws.xcat, self.xld)
             d_fc = d_feat
+            s_dfc = ops.absmax(rows, 256, d_fc, 256, self.new_slot())
         ops.gemm_split_tn(2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256,
-                              splitk=_splitk(2592, 256, rows), colsum=g["b_base_fc1"])
+                              splitk=_splitk(2592, 256, rows), colsum=g["b_base_fc1"], a_max=ws.s_f2, b_max=s_dfc)
         if ws.f2_bits is not None and self.relu_bits:
             ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2_bits,
-                              ldm=ops.RELU_WORDS, flags=ops.GEMM_RELU_BITS)
+                              ldm=ops.RELU_WORDS, flags=ops.GEMM_RELU_BITS, a_max=s_dfc)
         else:
             ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
-                              flags=ops.GEMM_RELU_MASK)
+                              flags=ops.GEMM_RELU_MASK, a_max=s_dfc)
         ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,
                         g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
 
@@ -440,10 +492,16 @@ class UnrealModel(object):
         p = self.p
         ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)
 
-    def pc_head_forward(self, rows, feat, ld, hp):
+    def pc_head_forward(self, rows, feat, ld, hp, ws=None):
+        """hp = relu(feat @ W_pc_fc1 + b).  `ws`: the workspace the features live in (its absmax slot of the fc rows is the
+        A scale in FF mode; LSTM outputs are bounded by 1: a slot holding 1.0)."""
         p = self.p
+        if self._use_lstm:
+            a_max = self._one
+        else:
+            a_max = ws.s_x if ws is not None and getattr(ws, "s_x", None) is not None else None
         ops.gemm_split_nt(rows, 2592, 256, feat, ld, self.shadow["pc_fc1_fwd"], hp, 2592, bias=p["b_pc_fc1"],
-                          flags=ops.GEMM_RELU)
+                          flags=ops.GEMM_RELU, a_max=a_max)
 
     # -- reference batch-1 runners (model.py:630-728) ---------------------------------------------------
     def _b1_ws(self):
@@ -475,16 +533,18 @@ class UnrealModel(object):
 
     def _run_trunk1(self, s_t, last_action_reward, state):
         self.refresh_shadows()                 # the caller may have changed the weights since the last call
+        self.begin_pass()
         ring, ws = self._stage([s_t['image']], last_action_reward)
-        scale = self.frame_scale
+        scale, bounded = self.frame_scale, self.lar_bounded
         self.frame_scale = 1.0 / 255.0
+        self.lar_bounded = False               # the caller's last_action_reward vector is arbitrary
         try:
             if self._use_lstm:
                 ws.c0[:256].copy_(state[0].reshape(-1))
                 ws.h0[:256].copy_(state[1].reshape(-1))
             feat, ld = self.trunk_forward(ring, ws, 1, 1, lar_from_ring=True, save_c1=False)
         finally:
-            self.frame_scale = scale
+            self.frame_scale, self.lar_bounded = scale, bounded
         return ws, feat, ld
 
     def run_base_policy_and_value(self, sess, s_t, last_action_reward, mode=""):
@@ -509,7 +569,7 @@ class UnrealModel(object):
     def run_pc_q_max(self, sess, s_t, last_action_reward):
         b1 = self._b1_ws()
         ws, feat, ld = self._run_trunk1(s_t, last_action_reward, self._zero_state())
-        self.pc_head_forward(1, feat, ld, b1["hp"])
+        self.pc_head_forward(1, feat, ld, b1["hp"], ws=ws)
         p = self.p
         ops.pc_deconv_fwd(1, self._action_size, b1["hp"], p["W_pc_deconv_v"], p["b_pc_deconv_v"],
                           p["W_pc_deconv_a"], p["b_pc_deconv_a"], qmax=b1["q"])

@@ -294,15 +294,18 @@ def reset_state(B, terminal_end, c, h):
 
 
 # ---- network -------------------------------------------------------------------------------------
-def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None, relu_bits=None):
-    """relu_bits: optional int16 [N * RELU_WORDS], bit (j % 16) of word j / 16 of a frame = f2[j] > 0."""
+def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None, relu_bits=None,
+                f2_max=None):
+    """relu_bits: optional int16 [N * RELU_WORDS], bit (j % 16) of word j / 16 of a frame = f2[j] > 0.
+    f2_max: optional absmax slot that receives max f2 (the A scale of the fc GEMM that follows)."""
     N = frame_idx.numel()
     _chk(frames, "u8"); _chk(frame_idx, "i32", N)
     _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192); _chk(b2, "f32", 32)
     _chk(f2_out, "f32", N * F2_DIM); _chk(c1_out, "f32", N * C1_DIM, optional=True)
     _chk(relu_bits, "i16", N * RELU_WORDS, "relu_bits", optional=True)
+    _chk(f2_max, "f32", 1, "f2_max", optional=True)
     _call("unreal_encoder_fwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W1), ptr(b1), ptr(W2), ptr(b2),
-          ptr(c1_out), ptr(f2_out), ptr(relu_bits))
+          ptr(c1_out), ptr(f2_out), ptr(relu_bits), ptr(f2_max))
 
 
 def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2):
@@ -324,9 +327,56 @@ def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, 
           ptr(mask), ldm, flags, splitk)
 
 
+class AbsmaxPool(object):
+    """Absmax slots (include/unreal_hip.h: one float on the device holding max |x| of a tensor) for one pass of the
+    trainer: `reset()` zeroes them all with one fill, `new()` hands out the next one.  A producer kernel maxes its
+    outputs into a slot, the fp16x2 GEMM that consumes the tensor derives the tensor's power-of-two scale from it."""
+
+    def __init__(self, device, n=1024):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.n, self.next = n, 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.next = 0
+
+    def new(self):
+        if self.next >= self.n:
+            raise RuntimeError("AbsmaxPool exhausted (%d slots): reset() it once per pass" % self.n)
+        self.next += 1
+        return self.buf[self.next - 1:self.next]
+
+
+_SCRATCH = {}
+
+
+def _scratch_slot(like):
+    """A zeroed slot for callers that pass no absmax of their own (tests, one-off launches): ring of 64, stream-ordered."""
+    dev = like.device
+    st = _SCRATCH.get(dev)
+    if st is None:
+        st = _SCRATCH[dev] = [torch.zeros(64, dtype=torch.float32, device=dev), 0]
+    st[1] = (st[1] + 1) % 64
+    slot = st[0][st[1]:st[1] + 1]
+    slot.zero_()
+    return slot
+
+
+def absmax(rows, cols, x, ld, slot):
+    """slot = max(slot, max |x[r][c]|) over the rows x cols view of x (row stride ld)."""
+    _chk(x, "f32", (rows - 1) * ld + cols, "x"); _chk(slot, "f32", 1, "slot")
+    _call("unreal_absmax_f32", rows, cols, ptr(x), ld, ptr(slot))
+    return slot
+
+
+def _absmax_of(x, rows, cols, ld, slot):
+    return slot if slot is not None else absmax(rows, cols, x, ld, _scratch_slot(x))
+
+
 class SplitWeights:
-    """bf16x3 shadow of one weight matrix as unreal_gemm_f32_split_nt wants its W operand: planes[t][n][k], rows padded
-    with zeros to a multiple of 32 k.  `refresh()` re-splits from the live fp32 weights (after an optimiser step)."""
+    """fp16x2 shadow of one weight matrix as unreal_gemm_f32_split_nt wants its W operand: planes[t][n][k] (t = hi, lo of
+    w * 2^k, k from the matrix's absmax slot `wmax`), rows padded with zeros to a multiple of 32 k.  `refresh()` re-reduces
+    the maximum and re-splits from the live fp32 weights (after an optimiser step)."""
 
     def __init__(self, src, rows, cols, ld_src, transpose, offset=0, row_perm=0):
         self.src, self.rows, self.cols, self.ld_src, self.transpose, self.offset = src, rows, cols, ld_src, transpose, offset
@@ -334,12 +384,23 @@ class SplitWeights:
         self.N, self.K = (cols, rows) if transpose else (rows, cols)
         self.ldw = (self.K + 31) // 32 * 32
         self.plane = self.N * self.ldw
-        self.planes = torch.zeros(3 * self.plane, dtype=torch.int16, device=src.device)
+        self.planes = torch.zeros(2 * self.plane, dtype=torch.int16, device=src.device)
+        self.wmax = torch.zeros(1, dtype=torch.float32, device=src.device)
         self.refresh()
 
     def refresh(self):
-        split_bf16x3(self.rows, self.cols, self.src[self.offset:], self.ld_src, self.transpose, self.planes, self.ldw,
-                     self.plane, self.row_perm)
+        self.wmax.zero_()
+        absmax(self.rows, self.cols, self.src[self.offset:], self.ld_src, self.wmax)
+        split_f16x2(self.rows, self.cols, self.src[self.offset:], self.ld_src, self.transpose, self.planes, self.ldw,
+                    self.plane, self.wmax, self.row_perm)
+
+
+def split_f16x2(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, wmax, row_perm=0):
+    _chk(src, "f32", (rows - 1) * ld_src + cols, "src"); _chk(wmax, "f32", 1, "wmax")
+    orows, ocols = (cols, rows) if transpose else (rows, cols)
+    _chk(dst, "i16", plane + (orows - 1) * ld_dst + ocols, "dst")
+    _call("unreal_split_f16x2", rows, cols, ptr(src), ld_src, int(bool(transpose)), int(row_perm), ptr(dst), ld_dst,
+          plane, ptr(wmax))
 
 
 def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, row_perm=0):
@@ -351,8 +412,9 @@ def split_bf16x3(rows, cols, src, ld_src, transpose, dst, ld_dst, plane, row_per
 
 
 class LstmKernelShadow:
-    """Gate-interleaved bf16x3 shadow of the WHOLE BasicLSTMCell kernel [K_x + 256, 1024] as unreal_lstm_step_fwd(x=...)
-    multiplies it: planes[t][1024][pad32(K_x) + 256] -- input rows, zero padding to a K tile, recurrent rows."""
+    """Gate-interleaved fp16x2 shadow of the WHOLE BasicLSTMCell kernel [K_x + 256, 1024] as unreal_lstm_step_fwd(x=...)
+    multiplies it: planes[t][1024][pad32(K_x) + 256] -- input rows, zero padding to a K tile, recurrent rows; one scale
+    (absmax slot) for the whole kernel."""
 
     def __init__(self, kernel, K_x):
         self.src, self.K_x, self.row_perm = kernel, K_x, 1
@@ -360,16 +422,22 @@ class LstmKernelShadow:
         self.N, self.K = 1024, self.kxpad + 256
         self.ldw = self.K
         self.plane = self.N * self.ldw
-        self.planes = torch.zeros(3 * self.plane, dtype=torch.int16, device=kernel.device)
+        self.planes = torch.zeros(2 * self.plane, dtype=torch.int16, device=kernel.device)
+        self.wmax = torch.zeros(1, dtype=torch.float32, device=kernel.device)
         self.refresh()
 
     def refresh(self):
-        split_bf16x3(self.K_x, 1024, self.src, 1024, True, self.planes, self.ldw, self.plane, 1)
-        split_bf16x3(256, 1024, self.src[self.K_x * 1024:], 1024, True, self.planes[self.kxpad:], self.ldw, self.plane, 1)
+        self.wmax.zero_()
+        absmax(self.K_x + 256, 1024, self.src, 1024, self.wmax)
+        split_f16x2(self.K_x, 1024, self.src, 1024, True, self.planes, self.ldw, self.plane, self.wmax, 1)
+        split_f16x2(256, 1024, self.src[self.K_x * 1024:], 1024, True, self.planes[self.kxpad:], self.ldw, self.plane,
+                    self.wmax, 1)
 
 
-def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):
-    """C = A[M,K] @ W[N,K]^T (fp32-grade, 3 x bf16 split operands on the bf16 matrix cores); W is a SplitWeights.
+def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1, a_max=None, c_max=None):
+    """C = A[M,K] @ W[N,K]^T (fp32-grade: fp16 hi + lo operands with per-tensor scales, 3 term pairs on the fp16 matrix
+    cores); W is a SplitWeights.  a_max: absmax slot covering A (None: reduced here with one extra launch); c_max: slot
+    that receives max |C|.
     mask: fp32 [M, ldm] with GEMM_RELU_MASK, or int16 bit words [M, ldm] with GEMM_RELU_BITS (encoder_fwd relu_bits)."""
     if W.N != N or W.K != K:
         raise ValueError("split weights are [%d,%d], GEMM wants [%d,%d]" % (W.N, W.K, N, K))
@@ -379,19 +447,38 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
         _chk(mask, "i16", (M - 1) * ldm + (N + 15) // 16, "mask bits")
     else:
         _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
-    _call("unreal_gemm_f32_split_nt", M, N, K, ptr(A), lda, ptr(W.planes), W.ldw, W.plane, ptr(C), ldc, ptr(bias),
-          ptr(mask), ldm, flags, splitk)
+    _chk(a_max, "f32", 1, "a_max", optional=True); _chk(c_max, "f32", 1, "c_max", optional=True)
+    if K < 64 and not (flags & GEMM_RELU_BITS):
+        # one or two K tiles: nothing to split for -- hi + lo carries 22 bits per element, which only pays off against the
+        # rounding of a long accumulation (at K = 3 the split result is ~2.5x the fp32 chain's error).  Such products (none
+        # on the trainer's path) go to the exact fp32-MFMA kernel with the weights the shadow was made from.
+        if W.transpose:          # src is [K][N]
+            gemm(False, False, M, N, K, A, lda, W.src[W.offset:], W.ld_src, C, ldc, bias, mask, ldm, flags, splitk)
+        else:                    # src is [N][K]
+            gemm(False, True, M, N, K, A, lda, W.src[W.offset:], W.ld_src, C, ldc, bias, mask, ldm, flags, splitk)
+        if c_max is not None:
+            absmax(M, N, C, ldc, c_max)
+        return
+    a_max = _absmax_of(A, M, K, lda, a_max)
+    _call("unreal_gemm_f32_split_nt", M, N, K, ptr(A), lda, ptr(a_max), ptr(W.planes), W.ldw, W.plane, ptr(W.wmax), ptr(C), ldc,
+          ptr(c_max), ptr(bias), ptr(mask), ldm, flags, splitk)
 
 
-def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None):
-    """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the bf16 matrix cores, split-K atomics into C);
-    colsum[N] += column sums of B (the bias gradient of the same layer) when given."""
+def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None, a_max=None, b_max=None):
+    """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the fp16 matrix cores, split-K atomics into C);
+    colsum[N] += column sums of B (the bias gradient of the same layer) when given.
+    a_max / b_max: absmax slots covering A / B (None: reduced here with one extra launch each)."""
     _chk(A, "f32", (K - 1) * lda + M, "A"); _chk(B, "f32", (K - 1) * ldb + N, "B"); _chk(C, "f32", (M - 1) * ldc + N, "C")
     _chk(colsum, "f32", N, "colsum", optional=True)
-    _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(colsum), splitk)
+    _chk(a_max, "f32", 1, "a_max", optional=True); _chk(b_max, "f32", 1, "b_max", optional=True)
+    a_max = _absmax_of(A, K, M, lda, a_max)
+    b_max = _absmax_of(B, K, N, ldb, b_max)
+    _call("unreal_gemm_f32_split_tn", M, N, K, ptr(A), lda, ptr(a_max), ptr(B), ldb, ptr(b_max), ptr(C), ldc, ptr(colsum),
+          splitk)
 
 
-def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256, x=None, ldx=0, Kx=0):
+def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=256, ld_h=256, x=None, ldx=0, Kx=0,
+                  x_max=None):
     """One BasicLSTMCell step with the gate math fused into the product.
     x None : gates (in: x-half pre-activations, out: activated gates) += h_prev @ Wh;
              Wh = SplitWeights(kernel recurrent rows, transpose=True, row_perm=1).
@@ -403,8 +490,11 @@ def lstm_step_fwd(rows, h_prev, Wh, gates, bias, c_prev, c_out, h_out, ld_hprev=
     _chk(bias, "f32", 1024, "bias"); _chk(c_prev, "f32", rows * 256, "c_prev"); _chk(c_out, "f32", rows * 256, "c_out")
     _chk(h_out, "f32", (rows - 1) * ld_h + 256, "h_out")
     _chk(x, "f32", (rows - 1) * ldx + Kx if x is not None else None, "x", optional=True)
-    _call("unreal_lstm_step_fwd", rows, ptr(x), ldx, Kx, ptr(h_prev), ld_hprev, ptr(Wh.planes), Wh.ldw, Wh.plane,
-          ptr(gates), ptr(bias), ptr(c_prev), ptr(c_out), ptr(h_out), ld_h)
+    _chk(x_max, "f32", 1, "x_max", optional=True)
+    if x is not None:        # |h_prev| < 1 is covered by the kernel; x needs its slot
+        x_max = _absmax_of(x, rows, Kx, ldx, x_max)
+    _call("unreal_lstm_step_fwd", rows, ptr(x), ldx, Kx, ptr(x_max), ptr(h_prev), ld_hprev, ptr(Wh.planes), Wh.ldw, Wh.plane,
+          ptr(Wh.wmax), ptr(gates), ptr(bias), ptr(c_prev), ptr(c_out), ptr(h_out), ld_h)
 
 
 def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):
@@ -415,15 +505,17 @@ def lstm_gates_fwd(rows, pre, bias, c_prev, gates_act, c_out, h_out, ld_h=256):
           ld_h)
 
 
-def lstm_gates_bwd(rows, dh_above, dh_rec, dc_io, gates_act, c_prev, c_new, dpre):
+def lstm_gates_bwd(rows, dh_above, dh_rec, dc_io, gates_act, c_prev, c_new, dpre, c_max0=None, c_max1=None):
     _chk(dh_above, "f32", rows * 256); _chk(dh_rec, "f32", rows * 256, optional=True)
     _chk(dc_io, "f32", rows * 256); _chk(gates_act, "f32", rows * 1024); _chk(c_prev, "f32", rows * 256)
     _chk(c_new, "f32", rows * 256); _chk(dpre, "f32", rows * 1024)
+    _chk(c_max0, "f32", 1, "c_max0", optional=True); _chk(c_max1, "f32", 1, "c_max1", optional=True)
     _call("unreal_lstm_gates_bwd", rows, ptr(dh_above), ptr(dh_rec), ptr(dc_io), ptr(gates_act), ptr(c_prev),
-          ptr(c_new), ptr(dpre))
+          ptr(c_new), ptr(dpre), ptr(c_max0), ptr(c_max1))
 
 
-def lstm_bptt_step(rows, d_gates, Wh, dh_above, dc_io, gates_act, c_prev, c_new, dpre):
+def lstm_bptt_step(rows, d_gates, Wh, dh_above, dc_io, gates_act, c_prev, c_new, dpre, a_max=None, c_max0=None,
+                   c_max1=None):
     """dh_rec = d_gates @ Wh^T and, in the same launch, the gate backward of the earlier step (dh = dh_above + dh_rec).
     Wh: SplitWeights(kernel recurrent rows, transpose=False) -- [256, 1024]."""
     if Wh.N != 256 or Wh.K != 1024 or getattr(Wh, "row_perm", 0):
@@ -431,8 +523,11 @@ def lstm_bptt_step(rows, d_gates, Wh, dh_above, dc_io, gates_act, c_prev, c_new,
     _chk(d_gates, "f32", rows * 1024, "d_gates"); _chk(dh_above, "f32", rows * 256); _chk(dc_io, "f32", rows * 256)
     _chk(gates_act, "f32", rows * 1024); _chk(c_prev, "f32", rows * 256); _chk(c_new, "f32", rows * 256)
     _chk(dpre, "f32", rows * 1024)
-    _call("unreal_lstm_bptt_step", rows, ptr(d_gates), ptr(Wh.planes), Wh.ldw, Wh.plane, ptr(dh_above), ptr(dc_io),
-          ptr(gates_act), ptr(c_prev), ptr(c_new), ptr(dpre))
+    _chk(a_max, "f32", 1, "a_max", optional=True); _chk(c_max0, "f32", 1, "c_max0", optional=True)
+    _chk(c_max1, "f32", 1, "c_max1", optional=True)
+    a_max = _absmax_of(d_gates, rows, 1024, 1024, a_max)
+    _call("unreal_lstm_bptt_step", rows, ptr(d_gates), ptr(a_max), ptr(Wh.planes), Wh.ldw, Wh.plane, ptr(Wh.wmax),
+          ptr(dh_above), ptr(dc_io), ptr(gates_act), ptr(c_prev), ptr(c_new), ptr(dpre), ptr(c_max0), ptr(c_max1))
 
 
 def linear_small_fwd(rows, K, NOUT, X, ldx, W, b, out, ldo):
@@ -506,11 +601,12 @@ def pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, qmax=None, action=None, target=None,
           ptr(target), ptr(mask), float(lam), float(grad_scale), ptr(d_dec), ptr(loss))
 
 
-def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba):
+def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_max=None):
     _chk(hp, "f32", N * F2_DIM); _chk(d_dec, "f32", N * PC_CELLS * (1 + A)); _chk(Wv, "f32", 512)
     _chk(Wa, "f32", 512 * A); _chk(d_hp, "f32", N * F2_DIM); _chk(dWv, "f32", 512); _chk(dbv, "f32", 1)
     _chk(dWa, "f32", 512 * A); _chk(dba, "f32", A)
-    _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(d_dec), ptr(Wv), ptr(Wa), ptr(d_hp), ptr(dWv), ptr(dbv),
+    _chk(dhp_max, "f32", 1, "dhp_max", optional=True)
+    _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(d_dec), ptr(Wv), ptr(Wa), ptr(d_hp), ptr(dhp_max), ptr(dWv), ptr(dbv),
           ptr(dWa), ptr(dba))
 
 

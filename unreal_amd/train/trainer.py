@@ -158,6 +158,9 @@ class Trainer(object):
         self.full_environment = self.environment
         self.full_ring = self.ring = self.environment.ring
         self.local_network.bind_frame_scale(self.environment.frame_scale)
+        # [last action | last reward] columns of the LSTM input: within 1 for the maze (rewards -1 / 0 / +1); host-fed
+        # actors feed raw rewards and measurement vectors, whose maximum is reduced per pass (model.encode_rows)
+        self.local_network.lar_bounded = self.env_type == "maze"
         self.experience = Experience(self.experience_history_size, ring=self.full_ring)
         B = self.Bg                                  # everything below is sized for ONE group
         lstm = self.use_lstm
@@ -278,6 +281,7 @@ class Trainer(object):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
         # weights are frozen while the replay fills: split them on the first call (or after an announced load)
         self.local_network.refresh_shadows(only_if_stale=self._fill_calls > 0)
+        self.local_network.begin_pass()
         for g in range(self.groups):
             self._select_group(g)
             self._fill_group()
@@ -450,24 +454,26 @@ class Trainer(object):
         ws = self.aux_ws                              # (allocates the per-branch workspace on first use)
         gws.ensure_pc(rows, A)
         feat, ld = self._sample_sequence()
-        net.pc_head_forward(B, feat, ld, self.boot_hp)
+        net.pc_head_forward(B, feat, ld, self.boot_hp, ws=self.boot_ws)
         ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], qmax=self.boot_qmax)
         ops.pc_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.boot_qmax, self.gamma_pc, gws.pc_R)
         feat, ld = self._aux_forward()
-        net.pc_head_forward(rows, feat, ld, gws.hp)
+        net.pc_head_forward(rows, feat, ld, gws.hp, ws=self.aux_ws)
         ops.gather_i32(self.ring.r_action, self.aux_ws.frame_idx[:rows], self.seq_act)
         ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask,
                           lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
                           loss=self.losses[3:4])
         d_hp = gws.d_f2
+        s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
         ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592,
-                              splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"])
-        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, net.shadow["pc_fc1_dgrad"], gws.d_feat, 256)
+                              splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
+                              a_max=net._one if self.use_lstm else self.aux_ws.s_x, b_max=s_dhp)
+        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, net.shadow["pc_fc1_dgrad"], gws.d_feat, 256, a_max=s_dhp)
         net.trunk_backward(self.ring, self.aux_ws, gws, Ta, B, gws.d_feat)
 
     def _train_vr(self):
@@ -509,7 +515,7 @@ class Trainer(object):
             bw.c0.zero_()
             bw.h0.zero_()
         feat, ld = net.trunk_forward(self.ring, bw, 1, 2 * B, lar_from_ring=True, save_c1=False)
-        net.pc_head_forward(B, feat, 2 * ld, self.boot_hp)
+        net.pc_head_forward(B, feat, 2 * ld, self.boot_hp, ws=self.boot2_ws)
         ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], qmax=self.boot_qmax)
         ops.pc_returns(self.ring, L, self.seq_idx2[0], self.seq_len2[0], self.boot_qmax, self.gamma_pc, gws.pc_R)
@@ -524,19 +530,21 @@ class Trainer(object):
         feat, ld = net.trunk_forward(self.ring, ws, Ta, 2 * B, lar_from_ring=True, save_c1=True)
         d_feat = gws.d_feat
         # pixel-control head on the even rows
-        net.pc_head_forward(rows, feat, 2 * ld, gws.hp)
+        net.pc_head_forward(rows, feat, 2 * ld, gws.hp, ws=self.aux2_ws)
         ops.gather_i32(self.ring.r_action, self.seq_idx2[0][:rows], self.seq_act)
         ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask2[0],
                           lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
                           loss=self.losses[3:4])
         d_hp = gws.d_hp
+        s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
         ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"])
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, 2 * ld, d_hp, 2592, g["W_pc_fc1"], 2592,
-                          splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"])
-        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, sh["pc_fc1_dgrad"], d_feat, 2 * 256)
+                          splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
+                          a_max=net._one if self.use_lstm else self.aux2_ws.s_x, b_max=s_dhp)
+        ops.gemm_split_nt(rows, 256, 2592, d_hp, 2592, sh["pc_fc1_dgrad"], d_feat, 2 * 256, a_max=s_dhp)
         # value head on the odd rows
         net.value_forward(rows, feat[ld:], 2 * ld, self.aux_v)
         ops.vr_loss_grad(rows, self.aux_v, self.aux_R, self.seq_mask2[1], self.grad_scale, self.aux_dv, self.losses[4:5])
@@ -566,7 +574,8 @@ class Trainer(object):
     def compute_gradients(self):
         """Rollout + the four loss branches; leaves the local mean gradient in local_network.grads.flat."""
         net = self.local_network
-        net.refresh_shadows()                  # bf16x3 weight planes follow the last optimiser step / load
+        net.refresh_shadows()                  # fp16x2 weight planes follow the last optimiser step / load
+        net.begin_pass()                       # absmax slots of this pass (fp16x2 GEMM scales)
         self._rollout()
         net.grads.flat.zero_()
         self.losses.zero_()
