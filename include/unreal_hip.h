@@ -124,10 +124,13 @@ int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float
                        float* f2_out /*[N][2592]*/,
                        uint16_t* relu_bits /*nullable [N][81][2]: bit c of word [n][pos][h] = f2[n][pos][16h + c] > 0,
                                              i.e. bit (j % 16) of word j / 16 of row n; UNREAL_GEMM_RELU_BITS reads it */,
-                       float* f2_absmax /*nullable absmax slot: max of f2_out, see unreal_absmax_f32*/, void* stream);
+                       float* f2_absmax /*nullable absmax slot: max of f2_out, see unreal_absmax_f32*/,
+                       float* c1_absmax /*nullable absmax slot: max of the conv1 activation (c1_out)*/, void* stream);
+/* c1_absmax / d2_absmax: absmax slots covering c1_saved / d2 (the kernel keeps both as fp16 hi + lo planes with one
+ * power-of-two scale per tensor, like the split GEMMs; the round-2 operand format needed none). */
 int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,
-                       const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2, float* db2,
-                       void* stream);
+                       const float* c1_saved, const float* c1_absmax, const float* d2, const float* d2_absmax, float* dW1,
+                       float* db1, float* dW2, float* db2, void* stream);
 
 /* ---- dense layers: tf.matmul call sites model/model.py:314,334,423 and BasicLSTMCell 110,346-351 -- */
 int unreal_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, int lda, const float* B,

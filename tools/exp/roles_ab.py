@@ -31,10 +31,15 @@ def grads():
     return [torch.zeros(n, device=dev) for n in (3072, 16, 8192, 32)]
 
 
+c1_max = c1.abs().max().reshape(1).contiguous()       # absmax slots (fp16x2 planes: per-tensor scales)
+d2_max = d2.abs().max().reshape(1).contiguous()
+
+
 def run(which, g, n=N):
     args = (n, P(pool.data_ptr()), P(idx.data_ptr()), ctypes.c_float(1.0 / 255), P(W2.data_ptr()), P(c1.data_ptr()),
-            P(d2.data_ptr()), P(g[0].data_ptr()), P(g[1].data_ptr()), P(g[2].data_ptr()), P(g[3].data_ptr()), P(st))
-    rc = lib.exp_encoder_bwd_phases(7, *args) if which < 0 else lib.exp_encoder_bwd_roles(which, *args)
+            P(d2.data_ptr()), P(g[0].data_ptr()), P(g[1].data_ptr()), P(g[2].data_ptr()), P(g[3].data_ptr()))
+    rc = lib.exp_encoder_bwd_phases(7, *args, P(st)) if which < 0 else lib.exp_encoder_bwd_roles(
+        which, *args, P(c1_max.data_ptr()), P(d2_max.data_ptr()), P(st))
     assert rc == 0, rc
 
 

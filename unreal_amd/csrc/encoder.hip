@@ -272,7 +272,7 @@ static_assert(2 * FWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS")
 template <bool TWO>
 __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp, float* __restrict__ c1_out,
                                             const u32x4v (&w1)[6][3], const int (&koff)[6], const f32x4& bias, float scale,
-                                            int ta, int tb, int i, int q) {
+                                            int ta, int tb, int i, int q, float& c1_max) {
   const int pa = ta * 16 + i, pb = tb * 16 + i;
   const uint8_t* fa = fr + (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
   const uint8_t* fb = fr + (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
@@ -301,6 +301,7 @@ __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(scale * acc[r] + bias[r], 0.f);
     if (c1_out) *reinterpret_cast<f32x4*>(c1_out + pos * C1_CH + 4 * q) = v;
+    c1_max = fmaxf(fmaxf(c1_max, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
     u32x2v pl[3];
     split4(v, pl);
 #pragma unroll
@@ -314,9 +315,10 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
                                                              const float* __restrict__ W1, const float* __restrict__ b1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2,
                                                              float* __restrict__ c1_out, float* __restrict__ f2_out,
-                                                             uint16_t* __restrict__ relu_bits, float* f2_absmax) {
+                                                             uint16_t* __restrict__ relu_bits, float* f2_absmax,
+                                                             float* c1_absmax) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
-  float f2_max = 0.f;                          // max of the outputs this lane has stored (they are >= 0)
+  float f2_max = 0.f, c1_max = 0.f;            // max of the outputs this lane has stored (they are >= 0)
   const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   uint8_t* fr = smem;
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       // 25 tiles over 4 waves = 7 + 6 + 6 + 6: the extra tile goes to an upper-K wave (gw = 2), which has no output
       // epilogue to do after conv2
       for (int tt = (gw + 2) & 3; tt < 25; tt += 8) {
-        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt + 4, i + zero, q);
-        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt, i + zero, q);
+        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt + 4, i + zero, q, c1_max);
+        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt, i + zero, q, c1_max);
       }
     }
     WG_BARRIER();     // [F1] c1 planes complete; FR dead
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     }
   }
   absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)
+  absmax_commit(c1_absmax, c1_max);       // the scale of the c1 planes in unreal_encoder_bwd
 }
 
 #ifdef UNREAL_ABLATE     // ---- round-2 backward kernel: kept as the A/B reference of tools/exp/roles_ab.py, not in the product ----
@@ -774,36 +777,37 @@ extern "C" {
 
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
                        const float* b1, const float* W2, const float* b2, float* c1_out, float* f2_out,
-                       uint16_t* relu_bits, float* f2_absmax, void* stream) {
+                       uint16_t* relu_bits, float* f2_absmax, float* c1_absmax, void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W1 || !b1 || !W2 || !b2 || !f2_out) return UNREAL_EINVAL;
   int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
   if (relu_bits)
     hipLaunchKernelGGL(encoder_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax);
   else
     hipLaunchKernelGGL(encoder_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax);
   return unreal_launch_status();
 }
 
 int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,
-                       const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2, float* db2,
-                       void* stream) {
+                       const float* c1_saved, const float* c1_absmax, const float* d2, const float* d2_absmax, float* dW1,
+                       float* db1, float* dW2, float* db2, void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W2 || !c1_saved || !d2 || !dW1 || !db1 || !dW2 || !db2)
     return UNREAL_EINVAL;
+  if (ENC_BWD_F16 && (!c1_absmax || !d2_absmax)) return UNREAL_EINVAL;
   int blocks = min(N, 256);             // one 512-thread workgroup per CU (4 consumer + 4 producer waves), a frame at a time
   hipLaunchKernelGGL((encoder_bwd_roles_kernel<7, true>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, N, frames,
-                     frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2);
+                     frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2, c1_absmax, d2_absmax);
   return unreal_launch_status();
 }
 
 #ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
 int exp_encoder_bwd_roles(int variant, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
                           const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
-                          float* db2, void* stream) {
+                          float* db2, const float* c1_absmax, const float* d2_absmax, void* stream) {
   int blocks = min(N, 256);             // one 512-thread workgroup per CU
 #define LAUNCH_R(P2C, P3ALL, ST) hipLaunchKernelGGL((encoder_bwd_roles_kernel<P2C, P3ALL, ST>), dim3(blocks), dim3(512), 0, \
-                                    (hipStream_t)stream, N, frames, frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2)
+                                    (hipStream_t)stream, N, frames, frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2, c1_absmax, d2_absmax)
   switch (variant) {
     case 0: LAUNCH_R(7, true, false); break;
     case 1: LAUNCH_R(6, true, false); break;

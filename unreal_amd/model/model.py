@@ -89,7 +89,7 @@ class PathWS(object):
     def __init__(self, rows, B, device, save_c1=True, lstm=True, xld=XLD):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
         self.rows, self.B, self.xld = rows, B, xld
-        self.s_x = self.s_f2 = self.s_x_cur = None     # absmax slots of the rows' LSTM input x / conv output (UnrealModel.encode_rows, per pass)
+        self.s_x = self.s_f2 = self.s_x_cur = self.s_c1 = None     # absmax slots of the rows' LSTM input x / conv output (UnrealModel.encode_rows, per pass)
         self.pass_id = None
         self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
         self.c1 = f(rows * ops.C1_DIM) if save_c1 else None
@@ -327,11 +327,12 @@ class UnrealModel(object):
         # running maximum: >= its rows', deterministic because the launches are stream-ordered).  Blocks encoded on
         # separate streams (host-fed half-batches, `actor_ring`) take fresh slots and merge them into the workspace's.
         if getattr(ws, "pass_id", None) != self.pass_id:
-            ws.s_f2, ws.s_x, ws.pass_id = self.new_slot(), self.new_slot(), self.pass_id
+            ws.s_f2, ws.s_x, ws.s_c1, ws.pass_id = self.new_slot(), self.new_slot(), self.new_slot(), self.pass_id
         own = actor_ring is not None
         s_f2, s_fc = (self.new_slot(), self.new_slot()) if own else (ws.s_f2, ws.s_x)
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
-                        p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2)
+                        p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2,
+                        c1_max=ws.s_c1 if c1 is not None else None)
         sh = self.shadow
         ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
                           flags=ops.GEMM_RELU, a_max=s_f2, c_max=s_fc)
@@ -468,14 +469,16 @@ class UnrealModel(object):
             s_dfc = ops.absmax(rows, 256, d_fc, 256, self.new_slot())
         ops.gemm_split_tn(2592, 256, rows, ws.f2, 2592, d_fc, 256, g["W_base_fc1"], 256,
                               splitk=_splitk(2592, 256, rows), colsum=g["b_base_fc1"], a_max=ws.s_f2, b_max=s_dfc)
+        s_df2 = self.new_slot()            # max |d_f2|: committed by the fc dgrad's epilogue, the d2 scale of the conv backward
         if ws.f2_bits is not None and self.relu_bits:
             ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2_bits,
-                              ldm=ops.RELU_WORDS, flags=ops.GEMM_RELU_BITS, a_max=s_dfc)
+                              ldm=ops.RELU_WORDS, flags=ops.GEMM_RELU_BITS, a_max=s_dfc, c_max=s_df2)
         else:
             ops.gemm_split_nt(rows, 2592, 256, d_fc, 256, sh["fc1_dgrad"], gws.d_f2, 2592, mask=ws.f2, ldm=2592,
-                              flags=ops.GEMM_RELU_MASK, a_max=s_dfc)
+                              flags=ops.GEMM_RELU_MASK, a_max=s_dfc, c_max=s_df2)
         ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], self.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2,
-                        g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
+                        g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"],
+                        c1_max=ws.s_c1, d2_max=s_df2)
 
     def heads_forward(self, rows, feat, ld, pi_out, v_out):
         p, A = self.p, self._action_size

@@ -295,7 +295,7 @@ def reset_state(B, terminal_end, c, h):
 
 # ---- network -------------------------------------------------------------------------------------
 def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None, relu_bits=None,
-                f2_max=None):
+                f2_max=None, c1_max=None):
     """relu_bits: optional int16 [N * RELU_WORDS], bit (j % 16) of word j / 16 of a frame = f2[j] > 0.
     f2_max: optional absmax slot that receives max f2 (the A scale of the fc GEMM that follows)."""
     N = frame_idx.numel()
@@ -303,18 +303,22 @@ def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n
     _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192); _chk(b2, "f32", 32)
     _chk(f2_out, "f32", N * F2_DIM); _chk(c1_out, "f32", N * C1_DIM, optional=True)
     _chk(relu_bits, "i16", N * RELU_WORDS, "relu_bits", optional=True)
-    _chk(f2_max, "f32", 1, "f2_max", optional=True)
+    _chk(f2_max, "f32", 1, "f2_max", optional=True); _chk(c1_max, "f32", 1, "c1_max", optional=True)
     _call("unreal_encoder_fwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W1), ptr(b1), ptr(W2), ptr(b2),
-          ptr(c1_out), ptr(f2_out), ptr(relu_bits), ptr(f2_max))
+          ptr(c1_out), ptr(f2_out), ptr(relu_bits), ptr(f2_max), ptr(c1_max))
 
 
-def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2):
+def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2, c1_max=None, d2_max=None):
+    """c1_max / d2_max: absmax slots covering c1_saved / d2 (None: reduced here with one extra launch each)."""
     N = frame_idx.numel()
+    _chk(c1_max, "f32", 1, "c1_max", optional=True); _chk(d2_max, "f32", 1, "d2_max", optional=True)
     _chk(frames, "u8"); _chk(frame_idx, "i32", N); _chk(W2, "f32", 8192)
     _chk(c1_saved, "f32", N * C1_DIM); _chk(d2, "f32", N * F2_DIM)
     _chk(dW1, "f32", 3072); _chk(db1, "f32", 16); _chk(dW2, "f32", 8192); _chk(db2, "f32", 32)
-    _call("unreal_encoder_bwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W2), ptr(c1_saved), ptr(d2),
-          ptr(dW1), ptr(db1), ptr(dW2), ptr(db2))
+    c1_max = _absmax_of(c1_saved, 1, N * C1_DIM, N * C1_DIM, c1_max)
+    d2_max = _absmax_of(d2, 1, N * F2_DIM, N * F2_DIM, d2_max)
+    _call("unreal_encoder_bwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W2), ptr(c1_saved), ptr(c1_max), ptr(d2),
+          ptr(d2_max), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2))
 
 
 def gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1):

@@ -559,8 +559,9 @@ class Trainer(object):
         self.draws.randint(2, self.rp_coin)
         self.draws.uniform(self.rp_u)
         ops.replay_sample_rp(self.ring, self.rp_coin, self.rp_u, ws.frame_idx[:3 * B], self.rp_class, self.rp_mode)
+        s_c1 = net.new_slot()              # max of the conv1 activation: the c1 scale of the conv backward below
         ops.encoder_fwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv1"],
-                        p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1)
+                        p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1, c1_max=s_c1)
         ops.linear_small_fwd(B, 7776, 3, ws.f2, 7776, p["W_rp_fc1"], p["b_rp_fc1"], self.rp_logits, 3)
         ops.rp_loss_grad(B, self.rp_logits, self.rp_class, self.grad_scale, None, self.rp_dlogits,
                          self.losses[5:6])
@@ -568,7 +569,8 @@ class Trainer(object):
                              g["W_rp_fc1"], g["b_rp_fc1"])
         ops.relu_mask(3 * B, 2592, gws.d_f2, 2592, ws.f2, 2592)
         ops.encoder_bwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv2"], ws.c1,
-                        gws.d_f2, g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"])
+                        gws.d_f2, g["W_base_conv1"], g["b_base_conv1"], g["W_base_conv2"], g["b_base_conv2"],
+                        c1_max=s_c1)           # (d_f2's maximum: reduced by the wrapper, 127 MB at 4096 actors)
 
     # ---------------------------------------------------------------------------------------------------
     def compute_gradients(self):
