@@ -262,17 +262,74 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
 // gw & 1 and K half gw >> 1 (4 chunks: 48 registers of W2 fragments) for all 6 position tiles; the two halves of K
 // are added in a FIXED order (lower + upper) through P, so the result does not depend on scheduling.
 // ------------------------------------------------------------------------------------------------
+// Operand format (round 3): ENC_FWD_F16 1 = fp16 hi + lo with one power-of-two scale per tensor, like gemm_split.hip:
+// conv1 takes 2 term pairs per tile and K chunk (W1 hi / lo x the exact pixel) instead of 3, conv2 3 (c1 hi / lo x W2
+// hi / lo: hh, hl, lh) instead of 6, and c1 is kept in LDS as two planes instead of three.  W1's and W2's maxima are
+// reduced once per kernel; c1's scale comes from a BOUND (it must be known before the first c1 value exists):
+// |c1[c]| <= 255 * frame_scale * sum_k |W1[k][c]| + |b1[c]| -- loose (by the 255 for the maze's 0 / 1 bytes), which
+// shortens the range over which hi + lo carry 22 bits but keeps the absolute error under 2^-32 of the largest c1.
+// ENC_FWD_F16 0 = round 2's three bf16 terms.
+#ifndef ENC_FWD_F16
+#define ENC_FWD_F16 1
+#endif
+constexpr int NPLF = ENC_FWD_F16 ? 2 : 3;
+typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
+#if ENC_FWD_F16
+typedef fh8 fop8;
+#define MFMA_FOP(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define SPLIT_MMA_FOP(A, B, C)       \
+  do {                               \
+    C = MFMA_FOP(A[1], B[0], C);     \
+    C = MFMA_FOP(A[0], B[1], C);     \
+    C = MFMA_FOP(A[0], B[0], C);     \
+  } while (0)
+#else
+typedef bf16x8 fop8;
+#define MFMA_FOP(a, b, c) MFMA_BF16(a, b, c)
+#define SPLIT_MMA_FOP(A, B, C) SPLIT_MMA(A, B, C)
+#endif
+// 4 fp32 -> NPLF planes of 4 sixteen-bit terms
+__device__ __forceinline__ void split4_fop(const f32x4& v, float scale, u32x2v (&pl)[3]) {
+#if ENC_FWD_F16
+  const f32x2v x01 = (f32x2v){v[0], v[1]} * scale, x23 = (f32x2v){v[2], v[3]} * scale;
+  const fh2 h01 = __builtin_convertvector(x01, fh2), h23 = __builtin_convertvector(x23, fh2);
+  const fh2 l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, f32x2v), fh2);
+  const fh2 l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, f32x2v), fh2);
+  pl[0] = (u32x2v){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+  pl[1] = (u32x2v){__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
+  pl[2] = pl[1];
+#else
+  (void)scale;
+  split4(v, pl);
+#endif
+}
+// 8 uint8 (two dwords) -> 8 sixteen-bit floats (exact in either format)
+__device__ __forceinline__ fop8 u8x8_to_fop(uint32_t w0, uint32_t w1) {
+#if ENC_FWD_F16
+  float f[8];
+  f[0] = (float)(w0 & 0xffu); f[1] = (float)((w0 >> 8) & 0xffu); f[2] = (float)((w0 >> 16) & 0xffu); f[3] = (float)(w0 >> 24);
+  f[4] = (float)(w1 & 0xffu); f[5] = (float)((w1 >> 8) & 0xffu); f[6] = (float)((w1 >> 16) & 0xffu); f[7] = (float)(w1 >> 24);
+  u32x4v r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(f[2 * e], f[2 * e + 1]));   // exact: integers
+  return __builtin_bit_cast(fop8, r);
+#else
+  return u8x8_to_bf16(w0, w1);
+#endif
+}
+
 constexpr int FWD_FR = FR_DMA * 1024;            // 21504: uint8 frame + DMA overshoot
 constexpr int FWD_X = FWD_FR;
-constexpr int FWD_P = FWD_X + 3 * XPL;           // 59904
-constexpr int FWD_LDS = FWD_P + 2 * 6 * 1024;    // 72192
+constexpr int FWD_P = FWD_X + NPLF * XPL;        // 59904 (bf16x3) / 47104 (fp16x2)
+constexpr int FWD_LDS = FWD_P + 2 * 6 * 1024;    // 72192 / 59392
 static_assert(2 * FWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
 // conv1 for TWO (or one) 16-position tiles, transposed: acc[r] = channel 4q + r at position 16 t + i
 template <bool TWO>
 __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp, float* __restrict__ c1_out,
                                             const u32x4v (&w1)[6][3], const int (&koff)[6], const f32x4& bias, float scale,
-                                            int ta, int tb, int i, int q, float& c1_max) {
+                                            int ta, int tb, int i, int q, float& c1_max, float c1_scale) {
   const int pa = ta * 16 + i, pb = tb * 16 + i;
   const uint8_t* fa = fr + (4 * (pa / 20)) * FRAME_ROW_BYTES + 12 * (pa % 20);
   const uint8_t* fb = fr + (4 * (pb / 20)) * FRAME_ROW_BYTES + 12 * (pb % 20);
@@ -280,17 +337,17 @@ __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp
 #pragma unroll
   for (int kc = 0; kc < 6; ++kc) {
     const uint32_t* pa32 = reinterpret_cast<const uint32_t*>(fa + koff[kc]);
-    const bf16x8 xa = u8x8_to_bf16(pa32[0], pa32[1]);
-    bf16x8 xb;
+    const fop8 xa = u8x8_to_fop(pa32[0], pa32[1]);
+    fop8 xb;
     if (TWO) {
       const uint32_t* pb32 = reinterpret_cast<const uint32_t*>(fb + koff[kc]);
-      xb = u8x8_to_bf16(pb32[0], pb32[1]);
+      xb = u8x8_to_fop(pb32[0], pb32[1]);
     }
 #pragma unroll
-    for (int t = 2; t >= 0; --t) {                   // smallest weight term first
-      const bf16x8 w = __builtin_bit_cast(bf16x8, w1[kc][t]);
-      acca = MFMA_BF16(w, xa, acca);
-      if (TWO) accb = MFMA_BF16(w, xb, accb);
+    for (int t = NPLF - 1; t >= 0; --t) {            // smallest weight term first
+      const fop8 w = __builtin_bit_cast(fop8, w1[kc][t]);
+      acca = MFMA_FOP(w, xa, acca);
+      if (TWO) accb = MFMA_FOP(w, xb, accb);
     }
   }
 #pragma unroll
@@ -303,9 +360,9 @@ __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp
     if (c1_out) *reinterpret_cast<f32x4*>(c1_out + pos * C1_CH + 4 * q) = v;
     c1_max = fmaxf(fmaxf(c1_max, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
     u32x2v pl[3];
-    split4(v, pl);
+    split4_fop(v, c1_scale, pl);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x2v*>(xp + u * XPL + xrow(pos) * XROW + 8 * q) = pl[u];
+    for (int u = 0; u < NPLF; ++u) *reinterpret_cast<u32x2v*>(xp + u * XPL + xrow(pos) * XROW + 8 * q) = pl[u];
   }
 }
 
@@ -327,14 +384,56 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
   const unsigned lds_fr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
   const int nt = gw & 1, kh = gw >> 1;         // conv2: this wave's n-tile and K half
 
-  u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], three bf16 terms
-  load_w1_bf16x3(W1, q, i, w1);
+  // fp16x2: power-of-two scales of W1, W2 (maxima reduced here, once) and of the c1 planes (from the bound above)
+  float S_W1 = 1.f, S_W2 = 1.f, S_C1 = 1.f;
+  if (ENC_FWD_F16) {
+    float* red = reinterpret_cast<float*>(smem);            // [16] L1 norm of W1 per channel, [16] max |W1|, [17] max |W2|
+    if (tid < 18) red[tid] = 0.f;
+    __syncthreads();
+    float l1 = 0.f, m1 = 0.f, m2 = 0.f;
+    const int c = tid & 15;
+    for (int k = tid >> 4; k < 192; k += 16) { const float w = fabsf(W1[k * 16 + c]); l1 += w; m1 = fmaxf(m1, w); }
+    for (int e = tid; e < 8192; e += 256) m2 = fmaxf(m2, fabsf(W2[e]));
+    atomicAdd(red + c, l1);
+    atomicMax(reinterpret_cast<unsigned int*>(red + 16), __float_as_uint(m1));
+    atomicMax(reinterpret_cast<unsigned int*>(red + 17), __float_as_uint(m2));
+    __syncthreads();
+    float bound = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bound = fmaxf(bound, 255.f * fabsf(scale) * red[k] + fabsf(b1[k]));
+    S_W1 = pow2_scale(red[16]);
+    S_W2 = pow2_scale(red[17]);
+    S_C1 = pow2_scale(bound);
+    __syncthreads();
+  }
+  const float scale1 = scale * pow2_inv(S_W1);             // conv1: un-scales W1 and applies the byte scale in one factor
+  const float inv_c2 = pow2_inv(S_C1) * pow2_inv(S_W2);    // conv2: exact (both powers of two; |exponents| <= 100 each
+                                                           // cannot meet here: c1's bound and W2's maximum are O(1))
+  u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
+  if (ENC_FWD_F16) {
+#pragma unroll
+    for (int kc = 0; kc < 6; ++kc) {
+      f32x4 lo4, hi4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo4[e] = W1[(32 * kc + 8 * q + e) * 16 + i];
+        hi4[e] = W1[(32 * kc + 8 * q + 4 + e) * 16 + i];
+      }
+      u32x2v lo[3], hi[3];
+      split4_fop(lo4, S_W1, lo);
+      split4_fop(hi4, S_W1, hi);
+#pragma unroll
+      for (int t = 0; t < NPLF; ++t) w1[kc][t] = (u32x4v){lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+    }
+  } else {
+    load_w1_bf16x3(W1, q, i, w1);
+  }
   int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
 #pragma unroll
   for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
   const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * q);
   // conv2: B[k = 32kc + 8q + j][col = n = 16nt + i] = W2[(tap = 2kc + (q>>1)) * 16 + 8(q&1) + j][n], kc = 4kh + c
-  bf16x8 w2[4][3];
+  fop8 w2[4][NPLF];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int k0 = 32 * (4 * kh + c) + 8 * q;
@@ -345,12 +444,12 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       hi4[j] = W2[(k0 + 4 + j) * 32 + 16 * nt + i];
     }
     u32x2v lo[3], hi[3];
-    split4(lo4, lo);
-    split4(hi4, hi);
+    split4_fop(lo4, S_W2, lo);
+    split4_fop(hi4, S_W2, hi);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < NPLF; ++t) {
       const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-      w2[c][t] = __builtin_bit_cast(bf16x8, w4);
+      w2[c][t] = __builtin_bit_cast(fop8, w4);
     }
   }
   const float bias2 = b2[16 * nt + i];
@@ -380,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       // 25 tiles over 4 waves = 7 + 6 + 6 + 6: the extra tile goes to an upper-K wave (gw = 2), which has no output
       // epilogue to do after conv2
       for (int tt = (gw + 2) & 3; tt < 25; tt += 8) {
-        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt + 4, i + zero, q, c1_max);
-        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale, tt, tt, i + zero, q, c1_max);
+        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale1, tt, tt + 4, i + zero, q, c1_max, S_C1);
+        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale1, tt, tt, i + zero, q, c1_max, S_C1);
       }
     }
     WG_BARRIER();     // [F1] c1 planes complete; FR dead
@@ -400,11 +499,12 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       for (int c = 0; c < 4; ++c) {
         const int tap = 2 * (4 * kh + c) + (q >> 1);
         const unsigned char* src = xp + xrow(p1 + (tap >> 2) * 20 + (tap & 3)) * XROW + 16 * (q & 1);
-        bf16x8 af[3];
+        fop8 af[NPLF];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) af[t] = *reinterpret_cast<const bf16x8*>(src + t * XPL);
-        SPLIT_MMA(af, w2[c], a);
+        for (int t = 0; t < NPLF; ++t) af[t] = *reinterpret_cast<const fop8*>(src + t * XPL);
+        SPLIT_MMA_FOP(af, w2[c], a);
       }
+      if (ENC_FWD_F16) a *= inv_c2;              // back to c1 * W2 units before the two K halves meet
       if (kh) *reinterpret_cast<f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16) = a;
       else {
         // static index for the register array

@@ -407,8 +407,8 @@ __device__ __forceinline__ void build_image_r(unsigned char* ip, int tid, u32x4 
       const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu),
                   f3 = (float)(w >> 24);
 #if ENC_BWD_F16      // a byte is exact in fp16 too
-      o[d >> 1][2 * (d & 1)] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2v){f0, f1}, f16x2v));
-      o[d >> 1][2 * (d & 1) + 1] = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2v){f2, f3}, f16x2v));
+      o[d >> 1][2 * (d & 1)] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(f0, f1));     // exact: integers
+      o[d >> 1][2 * (d & 1) + 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(f2, f3));
 #else
       o[d >> 1][2 * (d & 1)] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
       o[d >> 1][2 * (d & 1) + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
