@@ -47,7 +47,7 @@ ENC_BWD_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS * ENC_BWD_MAC / ENC_BWD_BF16_PASS_MA
 ENC_BWD_R2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS * ENC_BWD_MAC / ENC_BWD_R2_PASS_MAC     # ~549
 FP32_MFMA_PEAK_TFLOPS = 157.3                                    # MI355X_MICROARCH.md, Peak FP32 (matrix)
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "r02_pmc_bench.json"                                  # in-situ rocprofv3 --pmc passes of THIS program
+PMC_FILE = "r03_pmc_bench.json"                                  # in-situ rocprofv3 --pmc passes of THIS program
 
 
 def build_trainer(args, rank, world, device):
@@ -235,14 +235,15 @@ def main():
     avg_ms = kt["ms"] / max(kt["launches"], 1)
     achieved = (2.0 * mac * frames_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r02_pmc_bench.json,
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r03_pmc_bench.json,
     # corrected as MI355X_MICROARCH.md prescribes: FETCH doubled), mean over the launches of its timed calls.
     # The PMC file records the launch it measured (frames per launch, actors, groups); the figure is scaled to THIS run's
     # frames per launch when the schedule is the profiled one (same groups: same mix of launches) and null otherwise.
     traffic, traffic_note = None, "no PMC summary for this kernel"
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        k = doc["kernels"][args.timed_kernel.replace("unreal_", "") + "_kernel"]
+        base = args.timed_kernel.replace("unreal_", "")
+        k = next(doc["kernels"][n] for n in (base + "_kernel", base + "_roles_kernel") if n in doc["kernels"])
         prof = doc.get("profiled_run", {"actors": 4096, "groups": 1, "frames_per_launch": 86016.0})
         if prof.get("groups", 1) == args.groups and frames_per_launch > 0:
             traffic = k["hbm_bytes_per_launch"] * frames_per_launch / float(prof["frames_per_launch"])

@@ -272,6 +272,18 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
 #ifndef ENC_FWD_F16
 #define ENC_FWD_F16 1
 #endif
+// ENC_FWD_SUBN 1 (fp16 form only): the uint8 pixel enters the MFMA as an fp16 SUBNORMAL -- the byte zero-extended to 16
+// bits IS the fp16 value b * 2^-24, and v_mfma_f32_16x16x32_f16 honours subnormal inputs (tools/exp/mfma_denorm_probe.py),
+// so the operand costs one byte permute per two pixels (4 VALU per 8-deep fragment) instead of 8 v_cvt_f32_ubyte + 4
+// v_cvt_pkrtz; the 2^24 goes into conv1's output factor (a power of two: results are bit-identical).
+#ifndef ENC_FWD_SUBN
+#define ENC_FWD_SUBN 1
+#endif
+// ENC_FWD_TAB 1: conv2's fragment addresses come from a per-lane table built once per kernel (24 sixteen-bit plane
+// offsets in 12 registers) instead of ~44 VALU of div / mod / swizzle arithmetic per position tile and frame.
+#ifndef ENC_FWD_TAB
+#define ENC_FWD_TAB 1
+#endif
 constexpr int NPLF = ENC_FWD_F16 ? 2 : 3;
 typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
@@ -306,7 +318,14 @@ __device__ __forceinline__ void split4_fop(const f32x4& v, float scale, u32x2v (
 }
 // 8 uint8 (two dwords) -> 8 sixteen-bit floats (exact in either format)
 __device__ __forceinline__ fop8 u8x8_to_fop(uint32_t w0, uint32_t w1) {
-#if ENC_FWD_F16
+#if ENC_FWD_F16 && ENC_FWD_SUBN
+  u32x4v r;        // halfword j = byte j (selector 0x0c = constant 0): fp16 subnormal b * 2^-24
+  r[0] = __builtin_amdgcn_perm(0u, w0, 0x0c010c00u);
+  r[1] = __builtin_amdgcn_perm(0u, w0, 0x0c030c02u);
+  r[2] = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);
+  r[3] = __builtin_amdgcn_perm(0u, w1, 0x0c030c02u);
+  return __builtin_bit_cast(fop8, r);
+#elif ENC_FWD_F16
   float f[8];
   f[0] = (float)(w0 & 0xffu); f[1] = (float)((w0 >> 8) & 0xffu); f[2] = (float)((w0 >> 16) & 0xffu); f[3] = (float)(w0 >> 24);
   f[4] = (float)(w1 & 0xffu); f[5] = (float)((w1 >> 8) & 0xffu); f[6] = (float)((w1 >> 16) & 0xffu); f[7] = (float)(w1 >> 24);
@@ -366,6 +385,20 @@ __device__ __forceinline__ void conv1_tiles(const uint8_t* fr, unsigned char* xp
   }
 }
 
+#ifdef ENC_FWD_STAMPS   // tools/exp/fwd_ab.py only: where a wave's cycles go (workgroup 3, s_memtime ticks summed over its frames)
+__device__ unsigned long long g_fstamp[4][8];
+#define FSTAMP(k)                                                  \
+  do {                                                             \
+    if (blockIdx.x == 3 && lane == 0) {                            \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+      g_fstamp[gw][k] += t_ - t_prev_;                             \
+      t_prev_ = t_;                                                \
+    }                                                              \
+  } while (0)
+#else
+#define FSTAMP(k)
+#endif
+
 template <bool BITS>
 __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
                                                              const int* __restrict__ frame_idx, float scale,
@@ -406,7 +439,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     S_C1 = pow2_scale(bound);
     __syncthreads();
   }
-  const float scale1 = scale * pow2_inv(S_W1);             // conv1: un-scales W1 and applies the byte scale in one factor
+  // conv1: un-scales W1 (and the 2^-24 of subnormal pixel operands) and applies the byte scale in one factor
+  const float scale1 = scale * pow2_inv(S_W1) * ((ENC_FWD_F16 && ENC_FWD_SUBN) ? 16777216.f : 1.f);
   const float inv_c2 = pow2_inv(S_C1) * pow2_inv(S_W2);    // conv2: exact (both powers of two; |exponents| <= 100 each
                                                            // cannot meet here: c1's bound and W2's maximum are O(1))
   u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
@@ -453,6 +487,24 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     }
   }
   const float bias2 = b2[16 * nt + i];
+#if ENC_FWD_TAB
+  // conv2 fragment of (position tile mt, K chunk c): byte offset inside a c1 plane of row (2oy + dy)*20 + 2ox + dx, channel
+  // half q & 1, for this lane's position 16mt + i and tap 2(4kh + c) + (q >> 1) = (dy, dx); two offsets per register
+  unsigned c2tab[12];
+#pragma unroll
+  for (int e2 = 0; e2 < 12; ++e2) {
+    unsigned pk = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int mt = (2 * e2 + h) >> 2, c = (2 * e2 + h) & 3;
+      const int pos = min(16 * mt + i, C2_POS - 1);
+      const int p1 = (2 * (pos / 9)) * 20 + 2 * (pos % 9);
+      const int tap = 2 * (4 * kh + c) + (q >> 1);
+      pk |= (unsigned)(xrow(p1 + (tap >> 2) * 20 + (tap & 3)) * XROW + 16 * (q & 1)) << (16 * h);
+    }
+    c2tab[e2] = pk;
+  }
+#endif
 
   auto dma_frame = [&](int fidx) {             // uint8 frame (pool index fidx) -> FR (lane-linear 1 KiB pieces)
     const uint8_t* src = frames + (size_t)fidx * FRAME_BYTES;
@@ -471,9 +523,13 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
   // under conv2.  [F2] conv2 done (every wave has waited for its own DMA pieces first): P complete, FR of the next
   // frame complete, X dead.  The lower-K waves then add / store the outputs while the upper-K waves already run
   // conv1 of the next frame; P and X are rewritten only behind the next [F1] / [F2].
+#ifdef ENC_FWD_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int n = blockIdx.x; n < N; n += stride) {
     int zero;                                  // opaque 0, new every frame: keeps the address sets out of the registers
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    FSTAMP(0);
     {
       float* c1n = c1_out ? c1_out + (size_t)n * (C1_POS * C1_CH) : nullptr;
       // 25 tiles over 4 waves = 7 + 6 + 6 + 6: the extra tile goes to an upper-K wave (gw = 2), which has no output
@@ -483,13 +539,34 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
         else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale1, tt, tt, i + zero, q, c1_max, S_C1);
       }
     }
+    FSTAMP(1);
     WG_BARRIER();     // [F1] c1 planes complete; FR dead
+    FSTAMP(2);
     if (n + stride < N) dma_frame(fidx_next);
     fidx_next = n + 2 * stride < N ? frame_idx[n + 2 * stride] : 0;
     // conv2: 6 position tiles x this wave's 4 K chunks
     f32x4 acc[6];
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if ENC_FWD_TAB
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int e = 4 * mt + c;
+        const unsigned off = (e & 1) ? (c2tab[e >> 1] >> 16) : (c2tab[e >> 1] & 0xffffu);
+        const unsigned char* src = xp + off;
+        fop8 af[NPLF];
+#pragma unroll
+        for (int t = 0; t < NPLF; ++t) af[t] = *reinterpret_cast<const fop8*>(src + t * XPL);
+        SPLIT_MMA_FOP(af, w2[c], a);
+      }
+      if (ENC_FWD_F16) a *= inv_c2;              // back to c1 * W2 units before the two K halves meet
+      if (kh) *reinterpret_cast<f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16) = a;
+      else acc[mt] = a;
+    }
+#else
 #pragma unroll 1
     for (int mt = 0; mt < 6; ++mt) {
       const int pos = min(16 * mt + i + zero, C2_POS - 1);
@@ -518,8 +595,12 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
         }
       }
     }
+#endif
+    FSTAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next frame have landed
+    FSTAMP(4);
     WG_BARRIER();     // [F2]
+    FSTAMP(5);
     if (!kh) {
       float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
       uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
@@ -541,6 +622,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
         }
       }
     }
+    FSTAMP(6);
   }
   absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)
   absmax_commit(c1_absmax, c1_max);       // the scale of the c1 planes in unreal_encoder_bwd
@@ -901,6 +983,17 @@ int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float
   return unreal_launch_status();
 }
 
+#ifdef ENC_FWD_STAMPS   // tools/exp only
+int exp_read_fstamps(unsigned long long* host32, int reset) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(host32, HIP_SYMBOL(g_fstamp), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fstamp), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 #ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
 int exp_encoder_bwd_roles(int variant, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
                           const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
