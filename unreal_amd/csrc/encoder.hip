@@ -277,12 +277,22 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
 // so the operand costs one byte permute per two pixels (4 VALU per 8-deep fragment) instead of 8 v_cvt_f32_ubyte + 4
 // v_cvt_pkrtz; the 2^24 goes into conv1's output factor (a power of two: results are bit-identical).
 #ifndef ENC_FWD_SUBN
-#define ENC_FWD_SUBN 1
+#define ENC_FWD_SUBN 0
 #endif
 // ENC_FWD_TAB 1: conv2's fragment addresses come from a per-lane table built once per kernel (24 sixteen-bit plane
 // offsets in 12 registers) instead of ~44 VALU of div / mod / swizzle arithmetic per position tile and frame.
 #ifndef ENC_FWD_TAB
 #define ENC_FWD_TAB 1
+#endif
+// ENC_FWD_SYM 1 (needs ENC_FWD_TAB): every wave finishes 3 of its n-tile's 6 position tiles (it keeps those partial sums
+// in registers and hands the other 3 to its partner through P) instead of the lower-K waves finishing all 6 while the
+// upper-K waves idle at the next barrier (stamps: 2,800 vs 380 ticks of epilogue per frame); conv2's fragment reads run
+// ENC_FWD_PF steps ahead of the MFMAs that consume them.
+#ifndef ENC_FWD_SYM
+#define ENC_FWD_SYM 1
+#endif
+#ifndef ENC_FWD_PF
+#define ENC_FWD_PF 2
 #endif
 constexpr int NPLF = ENC_FWD_F16 ? 2 : 3;
 typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
@@ -496,7 +506,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     unsigned pk = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int mt = (2 * e2 + h) >> 2, c = (2 * e2 + h) & 3;
+      const int u = (2 * e2 + h) >> 2, c = (2 * e2 + h) & 3;
+      const int mt = ENC_FWD_SYM ? (u + 3 * kh) % 6 : u;      // SYM: a wave walks its OWN three tiles first
       const int pos = min(16 * mt + i, C2_POS - 1);
       const int p1 = (2 * (pos / 9)) * 20 + 2 * (pos % 9);
       const int tap = 2 * (4 * kh + c) + (q >> 1);
@@ -548,7 +559,43 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     f32x4 acc[6];
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if ENC_FWD_TAB
+#if ENC_FWD_TAB && ENC_FWD_SYM
+    {
+      // 24 steps s = 4u + c (u: tile in this wave's order, own tiles first; c: K chunk), fragments ENC_FWD_PF steps ahead
+      fop8 af[ENC_FWD_PF + 1][NPLF];
+      auto frag = [&](int st, fop8 (&dst)[NPLF]) {
+        const unsigned off = (st & 1) ? (c2tab[st >> 1] >> 16) : (c2tab[st >> 1] & 0xffffu);
+#pragma unroll
+        for (int t = 0; t < NPLF; ++t) dst[t] = *reinterpret_cast<const fop8*>(xp + off + t * XPL);
+      };
+#pragma unroll
+      for (int st = 0; st < ENC_FWD_PF; ++st) frag(st, af[st]);
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 24; ++st) {
+        const int u = st >> 2, c = st & 3;
+        if (st + ENC_FWD_PF < 24) frag(st + ENC_FWD_PF, af[(st + ENC_FWD_PF) % (ENC_FWD_PF + 1)]);
+        SPLIT_MMA_FOP(af[st % (ENC_FWD_PF + 1)], w2[c], a);
+        // program order inside the step: { MFMA, VALU, LDS read } x 3 -- the fragment requests of step st + PF go out in
+        // the shadow of this step's MFMAs -- and nothing crosses the step boundary (left alone, the scheduler sinks every
+        // read to just before its MFMA to save registers: read, lgkmcnt(0), MFMA, ...)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == 3) {
+          if (ENC_FWD_F16) a *= inv_c2;            // back to c1 * W2 units before the two K halves meet
+          if (u < 3) acc[u] = a;                   // own tile 3kh + u
+          else *reinterpret_cast<f32x4*>(pp + ((nt * 6 + (u - 3 * kh)) * 64 + lane) * 16) = a;   // partner's tile u - 3kh
+          a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+#elif ENC_FWD_TAB
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt) {
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -601,6 +648,29 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     FSTAMP(4);
     WG_BARRIER();     // [F2]
     FSTAMP(5);
+#if ENC_FWD_TAB && ENC_FWD_SYM
+    {
+      float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
+      uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int mt = 3 * kh + u;
+        const f32x4 part = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pos = 16 * mt + 4 * q + r;
+          // lower + upper K half: the sum of two floats does not depend on which wave held which
+          const float v = fmaxf((acc[u][r] + part[r]) + bias2, 0.f);
+          if (pos < C2_POS) dst[pos * C2_CH] = v;
+          f2_max = fmaxf(f2_max, pos < C2_POS ? v : 0.f);
+          if (BITS) {
+            const unsigned long long m = __ballot(v > 0.f);
+            if (i == 0 && pos < C2_POS) bits_q[(16 * mt + r) * 2] = (uint16_t)(m >> (16 * q));
+          }
+        }
+      }
+    }
+#else
     if (!kh) {
       float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
       uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
@@ -622,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
         }
       }
     }
+#endif
     FSTAMP(6);
   }
   absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)

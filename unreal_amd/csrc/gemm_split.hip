@@ -866,7 +866,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(int rows, int cols, const f
     for (int r = wave; r < rows; r += nw)
       for (int c = lane; c < cols; c += 64) m = fmaxf(m, fabsf(x[(size_t)r * ld + c]));
   }
-  absmax_commit(slot, m);
+  // a short kernel's waves all finish together and would all find the slot still at its old value (one ~12 ns atomic
+  // each, serialised: 2048 waves = 25 us for a 2.6 MB weight): one commit per WORKGROUP, and few workgroups
+  __shared__ float wm[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) absmax_commit(slot, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 
 }  // namespace
@@ -876,7 +882,7 @@ extern "C" {
 int unreal_absmax_f32(int rows, int cols, const float* x, int ld, float* slot, void* stream) {
   if (rows <= 0 || cols <= 0 || !x || !slot || ld < cols) return UNREAL_EINVAL;
   const long n = (long)rows * cols;
-  const int grid = (int)min((n + 1023) / 1024, 512L);
+  const int grid = (int)min((n + 8191) / 8192, 512L);        // >= 8 x 16 bytes per lane
   hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows, cols, x, ld, slot);
   return unreal_launch_status();
 }
@@ -928,8 +934,11 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   if (blocks128 >= 384) {
     a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
-    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+#ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (tools/exp/gemm_ab.py)
+#define SPLIT_NT_DEEP128 0
+#endif
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
