@@ -12,12 +12,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "tools", "exp", "build")
 VARIANTS = {                       # name -> -D flags
-    "base": ["-DENC_FWD_SUBN=0", "-DENC_FWD_TAB=0", "-DENC_FWD_SYM=0"],          # the kernel as of commit 49470c4
-    "tab": ["-DENC_FWD_SUBN=0", "-DENC_FWD_TAB=1", "-DENC_FWD_SYM=0"],
-    "sym": ["-DENC_FWD_SUBN=0", "-DENC_FWD_TAB=1", "-DENC_FWD_SYM=1", "-DENC_FWD_PF=2"],
-    "sym_pf3": ["-DENC_FWD_SUBN=0", "-DENC_FWD_TAB=1", "-DENC_FWD_SYM=1", "-DENC_FWD_PF=3"],
-    "sym_pf1": ["-DENC_FWD_SUBN=0", "-DENC_FWD_TAB=1", "-DENC_FWD_SYM=1", "-DENC_FWD_PF=1"],
-    "sym+subn": ["-DENC_FWD_SUBN=1", "-DENC_FWD_TAB=1", "-DENC_FWD_SYM=1", "-DENC_FWD_PF=2"],
+    "base": ["-DENC_FWD_MAGIC=0", "-DENC_FWD_FR2=0"],          # table-driven conv2 + symmetric epilogue + prefetch (commit 1)
+    "fr2": ["-DENC_FWD_MAGIC=0", "-DENC_FWD_FR2=1"],
+    "magic": ["-DENC_FWD_MAGIC=1", "-DENC_FWD_FR2=0"],
+    "fr2+magic": ["-DENC_FWD_MAGIC=1", "-DENC_FWD_FR2=1"],
 }
 for a in sys.argv[1:]:             # extra variants: name=-DX=1,-DY=2
     if "=" in a and not a.startswith("--"):

@@ -272,27 +272,29 @@ __device__ __forceinline__ void glds16(const uint8_t* gsrc, unsigned lds_dst) {
 #ifndef ENC_FWD_F16
 #define ENC_FWD_F16 1
 #endif
-// ENC_FWD_SUBN 1 (fp16 form only): the uint8 pixel enters the MFMA as an fp16 SUBNORMAL -- the byte zero-extended to 16
-// bits IS the fp16 value b * 2^-24, and v_mfma_f32_16x16x32_f16 honours subnormal inputs (tools/exp/mfma_denorm_probe.py),
-// so the operand costs one byte permute per two pixels (4 VALU per 8-deep fragment) instead of 8 v_cvt_f32_ubyte + 4
-// v_cvt_pkrtz; the 2^24 goes into conv1's output factor (a power of two: results are bit-identical).
-#ifndef ENC_FWD_SUBN
-#define ENC_FWD_SUBN 0
+// ENC_FWD_MAGIC 1 (fp16 form only): uint8 pixel -> fp16 with 4 byte permutes + 4 packed adds per 8-deep fragment instead
+// of 8 v_cvt_f32_ubyte + 4 v_cvt_pkrtz: the halfword 0x6400 | b IS 1024 + b (ulp 1 in [1024, 2048)), and subtracting 1024
+// is exact.  (Feeding the byte as an fp16 SUBNORMAL, b * 2^-24, needs the permutes alone, but the MFMA aligns its 32
+// products by their exponent FIELDS: a subnormal's leading zeros are lost bits of the adder -- 5e-4 relative error on 0 / 1
+// bytes, tools/exp/mfma_denorm_probe.py, profiles/r03_mfma_subnormal_probe.log.  Rejected.)
+#ifndef ENC_FWD_MAGIC
+#define ENC_FWD_MAGIC 1
 #endif
-// ENC_FWD_TAB 1: conv2's fragment addresses come from a per-lane table built once per kernel (24 sixteen-bit plane
-// offsets in 12 registers) instead of ~44 VALU of div / mod / swizzle arithmetic per position tile and frame.
-#ifndef ENC_FWD_TAB
-#define ENC_FWD_TAB 1
-#endif
-// ENC_FWD_SYM 1 (needs ENC_FWD_TAB): every wave finishes 3 of its n-tile's 6 position tiles (it keeps those partial sums
-// in registers and hands the other 3 to its partner through P) instead of the lower-K waves finishing all 6 while the
-// upper-K waves idle at the next barrier (stamps: 2,800 vs 380 ticks of epilogue per frame); conv2's fragment reads run
-// ENC_FWD_PF steps ahead of the MFMAs that consume them.
-#ifndef ENC_FWD_SYM
-#define ENC_FWD_SYM 1
-#endif
+// conv2's fragment addresses come from a per-lane table built once per kernel (24 sixteen-bit plane offsets in 12
+// registers) instead of ~44 VALU of div / mod / swizzle arithmetic per position tile and frame; every wave finishes 3 of
+// its n-tile's 6 position tiles (it keeps those partial sums in registers and hands the other 3 to its partner through
+// P) instead of the lower-K waves finishing all 6 while the upper-K waves idle at the next barrier; conv2's fragment
+// reads run ENC_FWD_PF steps ahead of the MFMAs that consume them.  (Round 3, tools/exp/fwd_ab.py: 1.45 -> 1.21 ms per
+// 81,920 frames, outputs bit-identical.)
 #ifndef ENC_FWD_PF
 #define ENC_FWD_PF 2
+#endif
+// ENC_FWD_FR2 1: two uint8 frame buffers, the LDS-DMA runs two frames ahead (80,896 B of LDS: still two workgroups per CU).
+// Measured neutral (tools/exp/fwd_ab.py, profiles/r03_encoder_fwd_ab.log: 1.20 vs 1.21 ms; with the magic conversion 1.15 vs
+// 1.12): the wait before [F2] is not the DMA -- vmcnt also counts the 25.6 KB of conv1 activations this wave has stored, and
+// at 4.2 TB/s of HBM traffic (2.6 write + 1.6 read) those drain slowly.  Off.
+#ifndef ENC_FWD_FR2
+#define ENC_FWD_FR2 0
 #endif
 constexpr int NPLF = ENC_FWD_F16 ? 2 : 3;
 typedef _Float16 fh8 __attribute__((ext_vector_type(8)));
@@ -328,13 +330,14 @@ __device__ __forceinline__ void split4_fop(const f32x4& v, float scale, u32x2v (
 }
 // 8 uint8 (two dwords) -> 8 sixteen-bit floats (exact in either format)
 __device__ __forceinline__ fop8 u8x8_to_fop(uint32_t w0, uint32_t w1) {
-#if ENC_FWD_F16 && ENC_FWD_SUBN
-  u32x4v r;        // halfword j = byte j (selector 0x0c = constant 0): fp16 subnormal b * 2^-24
-  r[0] = __builtin_amdgcn_perm(0u, w0, 0x0c010c00u);
-  r[1] = __builtin_amdgcn_perm(0u, w0, 0x0c030c02u);
-  r[2] = __builtin_amdgcn_perm(0u, w1, 0x0c010c00u);
-  r[3] = __builtin_amdgcn_perm(0u, w1, 0x0c030c02u);
-  return __builtin_bit_cast(fop8, r);
+#if ENC_FWD_F16 && ENC_FWD_MAGIC
+  u32x4v r;        // halfword j = 0x6400 | byte j (selector 4 = byte 0 of the constant) = fp16(1024 + b)
+  r[0] = __builtin_amdgcn_perm(0x64646464u, w0, 0x04010400u);
+  r[1] = __builtin_amdgcn_perm(0x64646464u, w0, 0x04030402u);
+  r[2] = __builtin_amdgcn_perm(0x64646464u, w1, 0x04010400u);
+  r[3] = __builtin_amdgcn_perm(0x64646464u, w1, 0x04030402u);
+  const fh8 k1024 = {1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+  return __builtin_bit_cast(fop8, r) - k1024;
 #elif ENC_FWD_F16
   float f[8];
   f[0] = (float)(w0 & 0xffu); f[1] = (float)((w0 >> 8) & 0xffu); f[2] = (float)((w0 >> 16) & 0xffu); f[3] = (float)(w0 >> 24);
@@ -349,9 +352,9 @@ __device__ __forceinline__ fop8 u8x8_to_fop(uint32_t w0, uint32_t w1) {
 }
 
 constexpr int FWD_FR = FR_DMA * 1024;            // 21504: uint8 frame + DMA overshoot
-constexpr int FWD_X = FWD_FR;
-constexpr int FWD_P = FWD_X + NPLF * XPL;        // 59904 (bf16x3) / 47104 (fp16x2)
-constexpr int FWD_LDS = FWD_P + 2 * 6 * 1024;    // 72192 / 59392
+constexpr int FWD_X = (1 + ENC_FWD_FR2) * FWD_FR;   // two frame buffers: the DMA runs two frames ahead
+constexpr int FWD_P = FWD_X + NPLF * XPL;
+constexpr int FWD_LDS = FWD_P + 2 * 6 * 1024;    // 80896 (fp16x2, two frame buffers)
 static_assert(2 * FWD_LDS <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
 // conv1 for TWO (or one) 16-position tiles, transposed: acc[r] = channel 4q + r at position 16 t + i
@@ -449,8 +452,8 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     S_C1 = pow2_scale(bound);
     __syncthreads();
   }
-  // conv1: un-scales W1 (and the 2^-24 of subnormal pixel operands) and applies the byte scale in one factor
-  const float scale1 = scale * pow2_inv(S_W1) * ((ENC_FWD_F16 && ENC_FWD_SUBN) ? 16777216.f : 1.f);
+  // conv1: un-scales W1 and applies the byte scale in one factor
+  const float scale1 = scale * pow2_inv(S_W1);
   const float inv_c2 = pow2_inv(S_C1) * pow2_inv(S_W2);    // conv2: exact (both powers of two; |exponents| <= 100 each
                                                            // cannot meet here: c1's bound and W2's maximum are O(1))
   u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
@@ -497,7 +500,6 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     }
   }
   const float bias2 = b2[16 * nt + i];
-#if ENC_FWD_TAB
   // conv2 fragment of (position tile mt, K chunk c): byte offset inside a c1 plane of row (2oy + dy)*20 + 2ox + dx, channel
   // half q & 1, for this lane's position 16mt + i and tap 2(4kh + c) + (q >> 1) = (dy, dx); two offsets per register
   unsigned c2tab[12];
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int u = (2 * e2 + h) >> 2, c = (2 * e2 + h) & 3;
-      const int mt = ENC_FWD_SYM ? (u + 3 * kh) % 6 : u;      // SYM: a wave walks its OWN three tiles first
+      const int mt = (u + 3 * kh) % 6;                      // a wave walks its OWN three tiles first
       const int pos = min(16 * mt + i, C2_POS - 1);
       const int p1 = (2 * (pos / 9)) * 20 + 2 * (pos % 9);
       const int tap = 2 * (4 * kh + c) + (q >> 1);
@@ -515,53 +517,56 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     }
     c2tab[e2] = pk;
   }
-#endif
 
-  auto dma_frame = [&](int fidx) {             // uint8 frame (pool index fidx) -> FR (lane-linear 1 KiB pieces)
+  // uint8 frame (pool index fidx) -> FR buffer `buf` (lane-linear 1 KiB pieces; wave gw issues pieces gw, gw + 4, ...)
+  auto dma_frame = [&](int fidx, int buf) {
     const uint8_t* src = frames + (size_t)fidx * FRAME_BYTES;
     for (int kk = gw; kk < FR_DMA; kk += 4) {
       const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);
-      glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_fr + 1024 * kk));
+      glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_fr + buf * FWD_FR + 1024 * kk));
     }
   };
   const int stride = gridDim.x;
-  dma_frame(frame_idx[blockIdx.x]);            // the launch guarantees gridDim.x <= N
-  int fidx_next = blockIdx.x + stride < N ? frame_idx[blockIdx.x + stride] : 0;     // fetched one frame ahead
+  dma_frame(frame_idx[blockIdx.x], 0);         // the launch guarantees gridDim.x <= N
+  if (ENC_FWD_FR2 && blockIdx.x + stride < N) dma_frame(frame_idx[blockIdx.x + stride], 1);
+  // index of the frame whose DMA is issued behind the next [F1]: two frames ahead (FR2) / one
+  int fidx_next = blockIdx.x + (1 + ENC_FWD_FR2) * stride < N ? frame_idx[blockIdx.x + (1 + ENC_FWD_FR2) * stride] : 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   WG_BARRIER();
 
-  // Two barriers per frame.  [F1] conv1 done: X complete, FR dead -> the DMA of the next frame starts and lands
-  // under conv2.  [F2] conv2 done (every wave has waited for its own DMA pieces first): P complete, FR of the next
-  // frame complete, X dead.  The lower-K waves then add / store the outputs while the upper-K waves already run
-  // conv1 of the next frame; P and X are rewritten only behind the next [F1] / [F2].
+  // Two barriers per frame.  [F1] conv1 done: X complete, the frame buffer conv1 read is dead -> the DMA of the frame TWO
+  // ahead starts into it (FR2: two frame buffers; with one buffer the next frame's DMA had only conv2 -- 3,600 ticks --
+  // to land and every wave waited ~1,400 ticks for it).  [F2] conv2 done: P complete, X dead; every wave has first
+  // waited until at most its own pieces of the newest DMA are outstanding (loads return in order: the pieces of the
+  // frame conv1 reads next were issued a whole frame earlier).  Then every wave finishes its three output tiles and
+  // goes on to conv1 of the next frame; P and X are rewritten only behind the next [F1] / [F2].
 #ifdef ENC_FWD_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
+  int buf = 0;
   for (int n = blockIdx.x; n < N; n += stride) {
-    int zero;                                  // opaque 0, new every frame: keeps the address sets out of the registers
+    int zero;                                  // opaque 0, new every frame: keeps conv1's address sets out of the registers
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
     FSTAMP(0);
     {
       float* c1n = c1_out ? c1_out + (size_t)n * (C1_POS * C1_CH) : nullptr;
-      // 25 tiles over 4 waves = 7 + 6 + 6 + 6: the extra tile goes to an upper-K wave (gw = 2), which has no output
-      // epilogue to do after conv2
+      const uint8_t* frn = fr + buf * FWD_FR;
+      // 25 tiles over 4 waves = 7 + 6 + 6 + 6
       for (int tt = (gw + 2) & 3; tt < 25; tt += 8) {
-        if (tt + 4 < 25) conv1_tiles<true>(fr, xp, c1n, w1, koff, bias1, scale1, tt, tt + 4, i + zero, q, c1_max, S_C1);
-        else conv1_tiles<false>(fr, xp, c1n, w1, koff, bias1, scale1, tt, tt, i + zero, q, c1_max, S_C1);
+        if (tt + 4 < 25) conv1_tiles<true>(frn, xp, c1n, w1, koff, bias1, scale1, tt, tt + 4, i + zero, q, c1_max, S_C1);
+        else conv1_tiles<false>(frn, xp, c1n, w1, koff, bias1, scale1, tt, tt, i + zero, q, c1_max, S_C1);
       }
     }
     FSTAMP(1);
-    WG_BARRIER();     // [F1] c1 planes complete; FR dead
+    WG_BARRIER();     // [F1] c1 planes complete; this frame's buffer is dead
     FSTAMP(2);
-    if (n + stride < N) dma_frame(fidx_next);
-    fidx_next = n + 2 * stride < N ? frame_idx[n + 2 * stride] : 0;
-    // conv2: 6 position tiles x this wave's 4 K chunks
-    f32x4 acc[6];
-#pragma unroll
-    for (int mt = 0; mt < 6; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#if ENC_FWD_TAB && ENC_FWD_SYM
+    const bool dma_now = n + (1 + ENC_FWD_FR2) * stride < N;
+    if (dma_now) dma_frame(fidx_next, ENC_FWD_FR2 ? buf : 0);
+    fidx_next = n + (2 + ENC_FWD_FR2) * stride < N ? frame_idx[n + (2 + ENC_FWD_FR2) * stride] : 0;
+    // conv2: this wave's n-tile and K half (4 chunks) of all 6 position tiles -- 24 steps s = 4u + c (u: tile in this
+    // wave's order, own tiles first; c: K chunk), fragments ENC_FWD_PF steps ahead
+    f32x4 acc[3];
     {
-      // 24 steps s = 4u + c (u: tile in this wave's order, own tiles first; c: K chunk), fragments ENC_FWD_PF steps ahead
       fop8 af[ENC_FWD_PF + 1][NPLF];
       auto frag = [&](int st, fop8 (&dst)[NPLF]) {
         const unsigned off = (st & 1) ? (c2tab[st >> 1] >> 16) : (c2tab[st >> 1] & 0xffffu);
@@ -595,105 +600,61 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
         }
       }
     }
-#elif ENC_FWD_TAB
-#pragma unroll
-    for (int mt = 0; mt < 6; ++mt) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int e = 4 * mt + c;
-        const unsigned off = (e & 1) ? (c2tab[e >> 1] >> 16) : (c2tab[e >> 1] & 0xffffu);
-        const unsigned char* src = xp + off;
-        fop8 af[NPLF];
-#pragma unroll
-        for (int t = 0; t < NPLF; ++t) af[t] = *reinterpret_cast<const fop8*>(src + t * XPL);
-        SPLIT_MMA_FOP(af, w2[c], a);
-      }
-      if (ENC_FWD_F16) a *= inv_c2;              // back to c1 * W2 units before the two K halves meet
-      if (kh) *reinterpret_cast<f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16) = a;
-      else acc[mt] = a;
-    }
-#else
-#pragma unroll 1
-    for (int mt = 0; mt < 6; ++mt) {
-      const int pos = min(16 * mt + i + zero, C2_POS - 1);
-      const int p1 = (2 * (pos / 9)) * 20 + 2 * (pos % 9);
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int tap = 2 * (4 * kh + c) + (q >> 1);
-        const unsigned char* src = xp + xrow(p1 + (tap >> 2) * 20 + (tap & 3)) * XROW + 16 * (q & 1);
-        fop8 af[NPLF];
-#pragma unroll
-        for (int t = 0; t < NPLF; ++t) af[t] = *reinterpret_cast<const fop8*>(src + t * XPL);
-        SPLIT_MMA_FOP(af, w2[c], a);
-      }
-      if (ENC_FWD_F16) a *= inv_c2;              // back to c1 * W2 units before the two K halves meet
-      if (kh) *reinterpret_cast<f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16) = a;
-      else {
-        // static index for the register array
-        switch (mt) {
-          case 0: acc[0] = a; break;
-          case 1: acc[1] = a; break;
-          case 2: acc[2] = a; break;
-          case 3: acc[3] = a; break;
-          case 4: acc[4] = a; break;
-          default: acc[5] = a; break;
-        }
-      }
-    }
-#endif
     FSTAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next frame have landed
+    // the frame conv1 reads next has landed: everything but this wave's pieces of the DMA just issued (6 for wave 0, 5 for
+    // the others; vector loads return in order, and no other vector load is in flight) must have returned
+    if (ENC_FWD_FR2 && dma_now) {
+      if (gw == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     FSTAMP(4);
     WG_BARRIER();     // [F2]
     FSTAMP(5);
-#if ENC_FWD_TAB && ENC_FWD_SYM
     {
-      float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
-      uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
+      // this wave's three tiles mt = 3kh + u: lower + upper K half (the sum of two floats does not depend on which wave
+      // held which), bias, ReLU; tiles 0..4 are whole, tile 5 holds position 80 alone (q = 0, r = 0)
+      f32x4 part[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) part[u] = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + 3 * kh + u) * 64 + lane) * 16);
+      float* dst = f2_out + (size_t)n * F2_DIM + (48 * kh + 4 * q) * C2_CH + 16 * nt + i;
+      // ReLU pattern: ballot bit 16q + i of step r = (position 4q + r of the tile, channel 16nt + i); word (pos, nt) of the
+      // frame's bit matrix.  Lane i < 4 of every q-group stores the word of r = i: one store per tile
+      uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 48 * kh + 4 * q + (i & 3)) * 2 + nt : nullptr;
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
-        const int mt = 3 * kh + u;
-        const f32x4 part = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16);
+        f32x4 v;
+        unsigned long long m[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int pos = 16 * mt + 4 * q + r;
-          // lower + upper K half: the sum of two floats does not depend on which wave held which
-          const float v = fmaxf((acc[u][r] + part[r]) + bias2, 0.f);
-          if (pos < C2_POS) dst[pos * C2_CH] = v;
-          f2_max = fmaxf(f2_max, pos < C2_POS ? v : 0.f);
+          v[r] = fmaxf((acc[u][r] + part[u][r]) + bias2, 0.f);
+          if (BITS) m[r] = __ballot(v[r] > 0.f);
+        }
+        if (u < 2) {                           // tiles 0, 1, 3, 4: whole
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(16 * u + r) * C2_CH] = v[r];
+          f2_max = fmaxf(fmaxf(f2_max, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
           if (BITS) {
-            const unsigned long long m = __ballot(v > 0.f);
-            if (i == 0 && pos < C2_POS) bits_q[(16 * mt + r) * 2] = (uint16_t)(m >> (16 * q));
+            const unsigned long long mi = (i & 2) ? ((i & 1) ? m[3] : m[2]) : ((i & 1) ? m[1] : m[0]);
+            if (i < 4) bits_q[(16 * u) * 2] = (uint16_t)(mi >> (16 * q));
+          }
+        } else {                               // tile 2 (whole) or tile 5 (position 80 only)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = !kh || (q | r) == 0;
+            if (ok) dst[(32 + r) * C2_CH] = v[r];
+            f2_max = fmaxf(f2_max, ok ? v[r] : 0.f);
+          }
+          if (BITS) {
+            const unsigned long long mi = (i & 2) ? ((i & 1) ? m[3] : m[2]) : ((i & 1) ? m[1] : m[0]);
+            if (i < 4 && (!kh || (q | i) == 0)) bits_q[32 * 2] = (uint16_t)(mi >> (16 * q));
           }
         }
       }
     }
-#else
-    if (!kh) {
-      float* dst = f2_out + (size_t)n * F2_DIM + 16 * nt + i;
-      uint16_t* bits_q = BITS ? relu_bits + ((size_t)n * C2_POS + 4 * q) * 2 + nt : nullptr;   // word (pos, nt), pos = 16mt + 4q + r
-#pragma unroll
-      for (int mt = 0; mt < 6; ++mt) {
-        const f32x4 part = *reinterpret_cast<const f32x4*>(pp + ((nt * 6 + mt) * 64 + lane) * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int pos = 16 * mt + 4 * q + r;
-          const float v = fmaxf((acc[mt][r] + part[r]) + bias2, 0.f);
-          if (pos < C2_POS) dst[pos * C2_CH] = v;
-          f2_max = fmaxf(f2_max, pos < C2_POS ? v : 0.f);
-          if (BITS) {
-            // ReLU pattern of the 16 channels this wave holds of 4 positions: ballot bit 16q + i = (position 4q + r of the
-            // tile, channel 16nt + i); the dgrad of the layer above reads 1 bit per element instead of the fp32 output
-            const unsigned long long m = __ballot(v > 0.f);
-            if (i == 0 && pos < C2_POS) bits_q[(16 * mt + r) * 2] = (uint16_t)(m >> (16 * q));
-          }
-        }
-      }
-    }
-#endif
     FSTAMP(6);
+    buf ^= ENC_FWD_FR2;
   }
   absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)
   absmax_commit(c1_absmax, c1_max);       // the scale of the c1 planes in unreal_encoder_bwd

@@ -404,12 +404,15 @@ __device__ __forceinline__ void build_image_r(unsigned char* ip, int tid, u32x4 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const uint32_t w = raw[k][d];
+#if ENC_BWD_F16      // a byte is exact in fp16 too: halfword 0x6400 | b = fp16(1024 + b), minus 1024 (exact) -- 2 byte permutes + 2
+                     // packed adds per 4 pixels instead of 4 v_cvt_f32_ubyte + 2 v_cvt_pkrtz (as in encoder_fwd)
+      typedef _Float16 fh2i __attribute__((ext_vector_type(2)));
+      const fh2i k1024 = {1024, 1024};
+      o[d >> 1][2 * (d & 1)] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(fh2i, __builtin_amdgcn_perm(0x64646464u, w, 0x04010400u)) - k1024);
+      o[d >> 1][2 * (d & 1) + 1] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(fh2i, __builtin_amdgcn_perm(0x64646464u, w, 0x04030402u)) - k1024);
+#else
       const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu),
                   f3 = (float)(w >> 24);
-#if ENC_BWD_F16      // a byte is exact in fp16 too
-      o[d >> 1][2 * (d & 1)] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(f0, f1));     // exact: integers
-      o[d >> 1][2 * (d & 1) + 1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(f2, f3));
-#else
       o[d >> 1][2 * (d & 1)] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
       o[d >> 1][2 * (d & 1) + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
 #endif
