@@ -32,7 +32,12 @@ while not tr._full:
     tr.process(None, 0)
 for _ in range(3):
     tr.process(None, 0)
+TRIALS = int(os.environ.get("GATE_TRIALS", 3))      # live operands of TRIALS different trainer states
+TRIAL = int(os.environ.get("GATE_TRIAL", 0))
+for _ in range(2 * TRIAL):
+    tr.process(None, 0)
 net.refresh_shadows()
+net.begin_pass()
 tr._rollout(); net.grads.flat.zero_(); tr.losses.zero_(); tr._train_base()
 torch.cuda.synchronize()
 rows = tr.n_step_TD * ACTORS
@@ -124,6 +129,14 @@ def err(C, R):
     return float(e.pow(2).mean().sqrt() / R.pow(2).mean().sqrt()), float(e.abs().max() / R.abs().max())
 
 
+def tail(C, R):
+    """|error| / max |R| at the 99.99th and 99.9999th percentile (the maximum of 2e8 outputs is one sample)"""
+    e = (C.double() - R).abs().flatten() / R.abs().max()
+    k = e.numel()
+    top = torch.topk(e[::1] if k <= (1 << 27) else e[::2], max(1, int(1e-4 * min(k, 1 << 27)))).values
+    return float(top[-1]), float(top[max(0, int(len(top) * 0.01) - 1)])
+
+
 cases = []
 # (name, kind, operands...)
 cases.append(("fc forward  f2 x W_fc1      [%d x 256, K 2592]" % rows, "nt", f2, W_fc1, True, 256, 2592, lambda: ref64(f2, W_fc1)))
@@ -147,12 +160,18 @@ for name, kind, A, B, transpose, N, K, reff in cases:
         def run32():
             C32.zero_()
             ops.gemm(True, False, A.shape[1], B.shape[1], A.shape[0], A, A.stride(0), B, B.stride(0), C32, B.shape[1], flags=ops.GEMM_ATOMIC if hasattr(ops, "GEMM_ATOMIC") else 4, splitk=sk)
-    run32(); torch.cuda.synchronize()
+    try:
+        run32(); torch.cuda.synchronize()
+    except ValueError as ex:            # (a layout the plain kernel's wrapper refuses: no yardstick for this case)
+        print("%s\n   skipped: %s" % (name, ex))
+        continue
     res["fp32_mfma"] = err(C32, R) + (timed(run32),)
+    tails = {"fp32_mfma": tail(C32, R)}
     for mode, label in ((0, "bf16x3_6pass"), (1, "f16x2_3pass")):
         C, run = (nt(libs[mode], mode, A, B, transpose, N, K) if kind == "nt" else tn(libs[mode], mode, A, B))
         run(); torch.cuda.synchronize()
         res[label] = err(C, R) + (timed(run),)
+        tails[label] = tail(C, R)
     if kind == "tn":
         for label, mode, fn in EXTRA_TN:
             C, run = tn(ctypes.CDLL(os.path.join(OUT, fn)), int(mode), A, B)
@@ -160,8 +179,11 @@ for name, kind, A, B, transpose, N, K, reff in cases:
             res[label] = err(C, R) + (timed(run),)
     g = res["f16x2_3pass"][0] <= res["fp32_mfma"][0] and res["f16x2_3pass"][1] <= res["fp32_mfma"][1]
     print("%s\n   %s" % (name, "\n   ".join("%-22s rms %.3e max %.3e %.3f ms" % ((k,) + v) for k, v in res.items())))
-    print("   gate (f16x2 error <= fp32-MFMA error, rms AND max): %s;  speed f16x2 vs bf16x3: %.2fx" % (
-        "PASS" if g else "FAIL", res["bf16x3_6pass"][2] / res["f16x2_3pass"][2]))
+    print("   |err| / max |R| at the 99.99 / 99.9999 percentile: " + "; ".join("%s %.3e / %.3e" % ((k,) + v) for k, v in tails.items()))
+    print("   gate (f16x2 error <= fp32-MFMA error, rms AND max): %s (rms %s, max %s: ratio %.2f);  speed f16x2 vs bf16x3: %.2fx" % (
+        "PASS" if g else "FAIL", "pass" if res["f16x2_3pass"][0] <= res["fp32_mfma"][0] else "fail",
+        "pass" if res["f16x2_3pass"][1] <= res["fp32_mfma"][1] else "fail", res["f16x2_3pass"][1] / res["fp32_mfma"][1],
+        res["bf16x3_6pass"][2] / res["f16x2_3pass"][2]))
     # dynamic range of the activation operand relative to its tensor maximum (what a per-tensor scale has to cover)
     a = A.abs().flatten()[::97]
     nz = a[a > 0]

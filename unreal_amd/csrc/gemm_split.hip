@@ -429,7 +429,9 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
       }
     return;
   }
-  // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip); with KW groups each parks its partial
+  // epilogue through LDS: every lane moves 16 B of one row (same as gemm.hip; storing the 32 x 32 accumulator registers
+  // as they stand -- 2 x 128 B per instruction, no LDS round trip -- measured 0.55-0.9x: profiles/r03_gemm_nt_ablate.log);
+  // with KW groups each parks its partial
   // tile in its own LDS image and the partials are summed group 0 first
   constexpr int CLD = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
