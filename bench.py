@@ -255,6 +255,11 @@ def main():
     except Exception:
         pass
     peak = ENC_BWD_PEAK_TFLOPS if "bwd" in args.timed_kernel else FP32_MFMA_PEAK_TFLOPS
+    bytes_per_frame = 57136.0 if "bwd" in args.timed_kernel else 57168.0      # DESIGN.md section 4 (fwd: frame in, f2 + c1 out)
+    alg_bytes = bytes_per_frame * frames_per_launch
+    ai = 2.0 * mac / bytes_per_frame
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    hbm_bound = ai < ridge
     out = {
         "metric": "env-steps/sec (whole node), UNREAL maze 84x84",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,19 +279,33 @@ def main():
                    "comm_ms_per_update": (sum(per_rank_comm) / len(per_rank_comm)) if world > 1 else 0.0,
                    "comm_ms_per_update_per_rank": [round(x, 4) for x in per_rank_comm] if world > 1 else [],
                    "total_loss": losses["total_loss"], "grad_norm": losses["grad_norm"]},
-        "roofline": {"kernel": args.timed_kernel, "bound": "mfma", "achieved": achieved,
-                     "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "peak_note": "fp32-equivalent: dense fp16 MFMA peak (2500 TF) over the kernel's 16-bit passes (conv2 "
-                                  "wgrad + dgrad x3, conv1 wgrad x2 since round 3: fp16 hi + lo planes).  The same achieved "
-                                  "rate against round 2's ceiling (6 / 6 / 3 bf16 passes, 549 TF) is %.3f; against the fp32 "
-                                  "MFMA peak (157.3) %.3f" % (achieved / ENC_BWD_R2_PEAK_TFLOPS, achieved / FP32_MFMA_PEAK_TFLOPS),
-                     "frac_vs_round2_ceiling": achieved / ENC_BWD_R2_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_unit": traffic_note,
-                     "algorithmic_bytes_per_launch": 57136.0 * frames_per_launch,
-                     "launches": kt["launches"], "avg_launch_ms": avg_ms,
-                     "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),
-                     "whole_path_frac_fp32_mfma": value * 69.67e6 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world),
-                     "whole_path_frac_hbm_u8": value * 114396.0 / (HBM_PEAK_GBS * 1e9 * world)},
+        # Which roof binds the dominant kernel: its arithmetic intensity (fp32-equivalent FLOP per algorithmic HBM byte)
+        # against the ridge of ITS ceilings (fp32-equivalent MFMA ceiling / 8 TB/s).  Since round 3 runs encoder_bwd's
+        # products in 3 / 3 / 2 fp16 passes (ceiling 992 TF) the kernel sits LEFT of the ridge (89 < 124 FLOP/B): HBM binds.
+        # Both fractions are reported; `bound` / `achieved` / `peak` / `frac` are the binding roof's.
+        "roofline": dict(
+            {"kernel": args.timed_kernel},
+            **({"bound": "hbm", "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else 0.0}
+               if hbm_bound else
+               {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}),
+            **{"arithmetic_intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+               "mfma_achieved_tflops": achieved, "mfma_peak_tflops": peak, "mfma_frac": achieved / peak,
+               "hbm_achieved_gbs": alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0, "hbm_peak_gbs": HBM_PEAK_GBS,
+               "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_ms > 0 else 0.0,
+               "peak_note": "mfma_peak = fp32-equivalent: dense fp16 MFMA peak (2500 TF) over the kernel's 16-bit passes "
+                            "(conv2 wgrad + dgrad x3, conv1 wgrad x2 since round 3: fp16 hi + lo planes).  The same achieved "
+                            "rate against round 2's ceiling (6 / 6 / 3 bf16 passes, 549 TF) is %.3f; against the fp32 MFMA "
+                            "peak (157.3) %.3f.  hbm: algorithmic bytes (57,136 B per frame: uint8 frame + saved conv1 "
+                            "activation + d_f2) over the HIP-event launch time, against 8 TB/s"
+                            % (achieved / ENC_BWD_R2_PEAK_TFLOPS, achieved / FP32_MFMA_PEAK_TFLOPS),
+               "frac_vs_round2_ceiling": achieved / ENC_BWD_R2_PEAK_TFLOPS,
+               "traffic": traffic, "traffic_unit": traffic_note,
+               "algorithmic_bytes_per_launch": alg_bytes,
+               "launches": kt["launches"], "avg_launch_ms": avg_ms,
+               "frames_per_launch": frames_per_launch, "share_of_step": kt["ms"] / (elapsed * 1e3),
+               "whole_path_frac_fp32_mfma": value * 69.67e6 / (FP32_MFMA_PEAK_TFLOPS * 1e12 * world),
+               "whole_path_frac_hbm_u8": value * 114396.0 / (HBM_PEAK_GBS * 1e9 * world)}),
     }
     if world == 1 and not args.no_cpu_baseline:
         hist_cpu = args.history          # the workload's own replay history (its fill is untimed, like the GPU's)
