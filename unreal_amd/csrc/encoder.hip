@@ -656,8 +656,20 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     FSTAMP(6);
     buf ^= ENC_FWD_FR2;
   }
-  absmax_commit(f2_absmax, f2_max);       // the A scale of the fc GEMM that reads f2 (gemm_split.hip, fp16x2)
-  absmax_commit(c1_absmax, c1_max);       // the scale of the c1 planes in unreal_encoder_bwd
+  // one commit per workgroup and slot (the frame buffer is dead: no DMA was issued behind the last frame's [F1], and the
+  // waves still in their epilogue only read P).  The 2,048 waves of a launch end within microseconds of each other: each
+  // would find the slots at their old values and issue its own serialised atomics
+  {
+    float* red = reinterpret_cast<float*>(smem);
+    f2_max = wave_max(f2_max);
+    c1_max = wave_max(c1_max);
+    if (lane == 0) { red[gw] = f2_max; red[4 + gw] = c1_max; }
+    __syncthreads();
+    if (gw == 0) {
+      absmax_commit(f2_absmax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));   // the A scale of the fc GEMM that reads f2
+      absmax_commit(c1_absmax, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));   // the scale of the c1 planes in unreal_encoder_bwd
+    }
+  }
 }
 
 #ifdef UNREAL_ABLATE     // ---- round-2 backward kernel: kept as the A/B reference of tools/exp/roles_ab.py, not in the product ----

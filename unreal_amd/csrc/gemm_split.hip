@@ -536,8 +536,21 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
         p.dc_io[g] = dc * f;
       }
     }
-    absmax_commit(p.c_absmax0, omax);       // max |d_gates| of the step just produced: the next step's A scale
-    absmax_commit(p.c_absmax1, omax);
+    // max |d_gates| of the step just produced: the next step's A scale.  One commit per WORKGROUP: the 4096 waves of a
+    // step finish together, all would find the slot at its old value and each issue its (serialised, ~12 ns) atomic
+    {
+      __shared__ float wmx[4 * KW];
+      omax = wave_max(omax);
+      if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = omax;
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        float m = wmx[0];
+#pragma unroll
+        for (int g = 1; g < 4 * KW; ++g) m = fmaxf(m, wmx[g]);
+        absmax_commit(p.c_absmax0, m);
+        absmax_commit(p.c_absmax1, m);
+      }
+    }
     return;
   }
   // FLAG_RELU_BITS: mask is a bit matrix (uint16 words, row stride ldm words, bit j % 16 of word j / 16 = column j kept)
@@ -589,7 +602,18 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
       }
     }
   }
-  if (p.c_absmax0) absmax_commit(p.c_absmax0, omax);    // (block-uniform pointer; every lane left the loop together)
+  if (p.c_absmax0) {                                    // (block-uniform pointer; every lane left the loop together)
+    __shared__ float wmx0[4 * KW];                      // one commit per workgroup (see the BPTT epilogue)
+    omax = wave_max(omax);
+    if ((threadIdx.x & 63) == 0) wmx0[threadIdx.x >> 6] = omax;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float m = wmx0[0];
+#pragma unroll
+      for (int g = 1; g < 4 * KW; ++g) m = fmaxf(m, wmx0[g]);
+      absmax_commit(p.c_absmax0, m);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

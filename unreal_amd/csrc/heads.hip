@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void linear_small_fwd_kernel(int rows, int K, 
 }
 
 // dX[row][k] (+)= sum_n dO[row][n] W[k][n];  dW[k][n] += sum_rows X[row][k] dO[row][n];  db[n] += sum_rows dO
-// thread <-> column k, block <-> chunk of rows; dO rows of the chunk staged in LDS.
+// thread <-> column k, block <-> chunk of rows; dO rows come through the scalar cache.
 template <int NOUT>
 __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, int rows_per_block,
                                                                const float* __restrict__ X, int ldx,
@@ -95,21 +95,20 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
                                                                const float* __restrict__ W, float* __restrict__ dX,
                                                                int lddx, int accumulate_dx, float* __restrict__ dW,
                                                                int dw_sk, int dw_sn, float* __restrict__ db) {
-  extern __shared__ float sdo[];   // [rows_per_block][NOUT]
+  // dO[row][n] has the same address in every lane (row comes from blockIdx / the loop counter): the compiler reads it
+  // through the scalar cache -- no LDS staging, no barrier, no broadcast ds_read per (row, n) in the loop
   const int k = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * rows_per_block;
   const int nr = min(rows_per_block, rows - r0);
-  for (int e = threadIdx.x; e < nr * NOUT; e += 256) sdo[e] = dO[(size_t)(r0 + e / NOUT) * ldo + (e % NOUT)];
-  __syncthreads();
   if (k >= K) return;
-  float w[NOUT], acc[NOUT];
+  float w[NOUT], acc[NOUT], sdb[NOUT];
 #pragma unroll
-  for (int n = 0; n < NOUT; ++n) { w[n] = W ? W[(size_t)k * NOUT + n] : 0.f; acc[n] = 0.f; }
+  for (int n = 0; n < NOUT; ++n) { w[n] = W ? W[(size_t)k * NOUT + n] : 0.f; acc[n] = 0.f; sdb[n] = 0.f; }
   // four rows per trip with their loads issued together (one load in flight per thread left the kernel at ~1 TB/s);
   // the sums run over the rows in the same order as a one-row loop
   int r = 0;
   for (; r + 4 <= nr; r += 4) {
-    float xv[4], old[4];
+    float xv[4], old[4], d[4][NOUT];
 #pragma unroll
     for (int u = 0; u < 4; ++u) xv[u] = X[(size_t)(r0 + r + u) * ldx + k];
     if (dX && accumulate_dx) {
@@ -117,13 +116,17 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
       for (int u = 0; u < 4; ++u) old[u] = dX[(size_t)(r0 + r + u) * lddx + k];
     }
 #pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) d[u][n] = dO[(size_t)(r0 + r + u) * ldo + n];
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
       float dx = 0.f;
 #pragma unroll
       for (int n = 0; n < NOUT; ++n) {
-        const float d = sdo[(r + u) * NOUT + n];
-        acc[n] += xv[u] * d;
-        dx += d * w[n];
+        acc[n] += xv[u] * d[u][n];
+        dx += d[u][n] * w[n];
+        sdb[n] += d[u][n];
       }
       if (dX) dX[(size_t)(r0 + r + u) * lddx + k] = accumulate_dx ? (old[u] + dx) : dx;
     }
@@ -134,9 +137,10 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
     float dx = 0.f;
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
-      float d = sdo[r * NOUT + n];
+      const float d = dO[row * ldo + n];
       acc[n] += xv * d;
       dx += d * w[n];
+      sdb[n] += d;
     }
     if (dX) {
       float* p = dX + row * lddx + k;
@@ -145,10 +149,9 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(int rows, int K, 
   }
 #pragma unroll
   for (int n = 0; n < NOUT; ++n) atomicAdd(dW + (size_t)k * dw_sk + (size_t)n * dw_sn, acc[n]);
-  if (db && blockIdx.x == 0 && threadIdx.x < NOUT) {
-    float s = 0.f;
-    for (int r = 0; r < nr; ++r) s += sdo[r * NOUT + threadIdx.x];
-    atomicAdd(db + threadIdx.x, s);
+  if (db && k == 0) {                    // every thread holds the same row sums of dO; one of the grid's column 0 adds them
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) atomicAdd(db + n, sdb[n]);
   }
 }
 
@@ -371,9 +374,9 @@ template <int NOUT>
 int launch_small_bwd(int rows, int K, const float* X, int ldx, const float* dO, int ldo, const float* W, float* dX,
                      int lddx, int acc, float* dW, int dw_sk, int dw_sn, float* db, hipStream_t st) {
   if (dw_sk == 0 && dw_sn == 0) { dw_sk = NOUT; dw_sn = 1; }
-  const int rpb = 64;
+  const int rpb = 128;
   dim3 grid((K + 255) / 256, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL((linear_small_bwd_kernel<NOUT>), grid, dim3(256), rpb * NOUT * sizeof(float), st, rows, K, rpb, X,
+  hipLaunchKernelGGL((linear_small_bwd_kernel<NOUT>), grid, dim3(256), 0, st, rows, K, rpb, X,
                      ldx, dO, ldo, W, dX, lddx, acc, dW, dw_sk, dw_sn, db);
   return unreal_launch_status();
 }
