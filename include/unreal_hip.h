@@ -232,12 +232,17 @@ int unreal_colsum(int rows, int cols, const float* X, int ld, float* out, void* 
 int unreal_relu_mask(int rows, int cols, float* d, int ldd, const float* src, int lds, void* stream);
 
 /* ---- pixel-control head (model/model.py:411-443, 542-557, 805-820) -------------------------------- */
-int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const float* bv, const float* Wa,
-                         const float* ba, float* qmax, const int* action, const float* target, const int* mask,
-                         float lambda, float grad_scale, float* d_dec, float* loss, void* stream);
-int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, const float* Wv, const float* Wa,
-                         float* d_hp, float* dhp_absmax /*nullable absmax slot: max |d_hp|*/, float* dWv, float* dbv,
-                         float* dWa, float* dba, void* stream);
+/* hp [N][2592] = relu(pc_fc1); both deconvolutions + dueling combine on the fp16 matrix cores with fp16 hi + lo operands
+ * (round 3): hp_absmax = absmax slot covering hp (committed by the pc_fc1 GEMM, c_absmax of unreal_gemm_f32_split_nt).
+ * Bootstrap mode (qmax != NULL): max_a Q per cell.  Training mode (d_dec != NULL): loss + dL/d(pre-activation) of both
+ * deconvs, and ddec_absmax (nullable slot) receives an upper bound of max |d_dec| -- the scale unreal_pc_deconv_bwd needs. */
+int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* hp_absmax, const float* Wv, const float* bv,
+                         const float* Wa, const float* ba, float* qmax, const int* action, const float* target,
+                         const int* mask, float lambda, float grad_scale, float* d_dec, float* ddec_absmax, float* loss,
+                         void* stream);
+int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* hp_absmax, const float* d_dec, const float* ddec_absmax,
+                         const float* Wv, const float* Wa, float* d_hp, float* dhp_absmax /*nullable absmax slot: max |d_hp|*/,
+                         float* dWv, float* dbv, float* dWa, float* dba, void* stream);
 
 /* ---- optimiser (train/rmsprop_applier.py:38-43, 83-93, 121) ---------------------------------------- */
 int unreal_grad_norm(const float* grad, long n, float* scratch /*256 floats*/, float* norm_out, void* stream);

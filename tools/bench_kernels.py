@@ -142,7 +142,9 @@ def main():
         hp = torch.relu(rnd(N * 2592))
         Wv, bv, Wa, ba = rnd(512) * .04, rnd(1), rnd(2048) * .04, rnd(4)
         qmax = torch.zeros(N * 400, device=DEV)
-        report("pc_deconv_fwd qmax N=%d" % N, timeit(lambda: ops.pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, qmax=qmax)),
+        s_hp, s_dd = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)      # absmax slots (the producers' in the trainer)
+        ops.absmax(N, 2592, hp, 2592, s_hp)
+        report("pc_deconv_fwd qmax N=%d" % N, timeit(lambda: ops.pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, qmax=qmax, hp_max=s_hp)),
                flop=2 * 207360.0 * N, bytes_=N * (10368 + 1600.0))
         act = torch.randint(0, 4, (N,), dtype=torch.int32, device=DEV)
         tgt = rnd(N * 400)
@@ -151,12 +153,12 @@ def main():
         loss = torch.zeros(1, device=DEV)
         report("pc_deconv_fwd train N=%d" % N,
                timeit(lambda: ops.pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, action=act, target=tgt, mask=mask, lam=0.05,
-                                                grad_scale=1.0, d_dec=d_dec, loss=loss)),
+                                                grad_scale=1.0, d_dec=d_dec, loss=loss, hp_max=s_hp, ddec_max=s_dd)),
                flop=2 * 207360.0 * N, bytes_=N * (10368 + 1600 + 8000.0))
         d_hp = torch.zeros(N * 2592, device=DEV)
         g = [torch.zeros(n, device=DEV) for n in (512, 1, 2048, 4)]
         report("pc_deconv_bwd N=%d" % N,
-               timeit(lambda: ops.pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, *g)), flop=2 * 2 * 207360.0 * N,
+               timeit(lambda: ops.pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, *g, hp_max=s_hp, ddec_max=s_dd)), flop=2 * 2 * 207360.0 * N,
                bytes_=N * (10368 * 2 + 8000.0))
 
     if not FILT or FILT in "env":

@@ -57,9 +57,17 @@ __global__ void lstm_gates_bwd_kernel(int rows, const float* __restrict__ dh_abo
   dc_io[g] = dc * f;
   m = fmaxf(fmaxf(m, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
   }
-  // max |d_gates| of this step: the A scale of the products that consume it (unreal_lstm_bptt_step, the fc dgrad)
-  absmax_commit(absmax0, m);
-  absmax_commit(absmax1, m);
+  // max |d_gates| of this step: the A scale of the products that consume it (unreal_lstm_bptt_step, the fc dgrad).
+  // One commit per workgroup: the launch's waves end together and would each issue their (serialised) atomics
+  __shared__ float wmx[4];               // blockDim.x = 256
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float mm = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+    absmax_commit(absmax0, mm);
+    absmax_commit(absmax1, mm);
+  }
 }
 
 // out[row][n] = X[row][:] . W[:, n] + b[n], NOUT <= 8; one wave per row
@@ -279,12 +287,14 @@ __global__ __launch_bounds__(256) void base_loss_grad_kernel(int rows, int A, co
       ent = H;
     }
   }
+  // one atomic per workgroup and loss: the three sums share a cache line and the launch's 1,280 waves end together
+  // (3,840 serialised atomics were most of this kernel's 53 us)
+  __shared__ float part[3][4];
   pl = wave_sum(pl); vl = wave_sum(vl); ent = wave_sum(ent);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(losses + 0, pl * grad_scale);
-    atomicAdd(losses + 1, vl * grad_scale);
-    atomicAdd(losses + 2, ent * grad_scale);
-  }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = pl; part[1][threadIdx.x >> 6] = vl; part[2][threadIdx.x >> 6] = ent; }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicAdd(losses + threadIdx.x, (((part[threadIdx.x][0] + part[threadIdx.x][1]) + part[threadIdx.x][2]) + part[threadIdx.x][3]) * grad_scale);
 }
 
 // value-replay loss l2_loss(R - v) = 0.5 * sum (R-v)^2 ; dv = -(R - v)
@@ -299,8 +309,11 @@ __global__ __launch_bounds__(256) void vr_loss_grad_kernel(int rows, const float
     dv[r] = on ? -grad_scale * diff : 0.f;
     if (on) l = 0.5f * diff * diff;
   }
+  __shared__ float part[4];              // one atomic per workgroup (see base_loss_grad_kernel)
   l = wave_sum(l);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, l * grad_scale);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (((part[0] + part[1]) + part[2]) + part[3]) * grad_scale);
 }
 
 // reward prediction: softmax over 3 logits, cross entropy with clipped probabilities

@@ -8,10 +8,12 @@
 //   out[2a+pa][2b+pb][co] = sum_{da,db in {0,1}} sum_ci in[a-da][b-db][ci] * W[pa+2da][pb+2db][co][ci]
 // Forward: the four parities read the SAME input rows, so they are packed side by side into the MFMA's N dimension:
 // ONE GEMM of M = 100 base positions (a,b), K = 4 taps x 32 channels, N = 4 parities x (1+A) channels = 20 of 32
-// columns (per-parity GEMMs would fill 5 of 16).  Operands are split into three bf16 terms when they are staged into
-// LDS (hp per frame, the weights once per workgroup) and multiplied as six term-pair v_mfma_f32_16x16x32_bf16, the
-// scheme and error level of csrc/gemm_split.hip.  The backward pass uses the same split planes; its weight gradient reduces
-// over positions (the row index of the LDS images), so its operands come through transposed LDS reads.
+// columns (per-parity GEMMs would fill 5 of 16).  Operands are split into fp16 hi + lo planes when they are staged into
+// LDS (hp per frame, the weights once per workgroup; round 2: three bf16 terms) under one power-of-two scale per tensor --
+// hp's from the absmax slot the pc_fc1 GEMM commits, the weights' reduced here, d_dec's from the slot the forward kernel
+// commits -- and multiplied as three term-pair v_mfma_f32_16x16x32_f16 (hh, hl, lh; round 2: six), the scheme and error
+// level of csrc/gemm_split.hip.  The backward pass uses the same planes; its weight gradient reduces over positions (the
+// row index of the LDS images), so its operands come through transposed LDS reads.
 // Same group/LDS organisation and MFMA operand convention as encoder.hip: the next frame's inputs are
 // fetched into registers behind the current frame's math, outputs leave through LDS in 16 B/lane rows.
 #include "common.h"
@@ -19,8 +21,7 @@
 namespace {
 
 constexpr int HP_LD = 36, HP_ROWS = 84;   // [81][32] + zero rows; row 81 = padding row
-constexpr int DEC_LD_F = 8;               // fwd: floats per output position in LDS
-constexpr int DEC_LD_B = 12;              // bwd: floats per position (bank spreading)
+constexpr int NPLP = 2;                   // fp16 hi + lo planes
 constexpr int WD_ELEMS = 4 * 4 * 2 * 4 * 16 * 4;   // 8192
 constexpr int HP_V = (C2_POS * 8 + 255) / 256;     // f32x4 per thread for one [81][32] image (3)
 constexpr int DD_V = (PC_CELLS * 8 / 4 + 255) / 256;   // f32x4 per thread for one [400][<=8] image (4)
@@ -28,6 +29,7 @@ constexpr int DD_V = (PC_CELLS * 8 / 4 + 255) / 256;   // f32x4 per thread for o
 struct PcFwdArgs {
   int N, A;
   const float* hp;          // [N][2592] relu(pc_fc1)
+  const float* hp_absmax;   // absmax slot covering hp (common.h): the scale of its fp16 planes
   const float* Wv; const float* bv; const float* Wa; const float* ba;
   // bootstrap mode
   float* qmax;              // [N][400] or null
@@ -37,6 +39,7 @@ struct PcFwdArgs {
   const int* mask;          // [N]
   float lambda, grad_scale;
   float* d_dec;             // [N][400][1+A]
+  float* ddec_absmax;       // nullable slot: max |d_dec|, the scale of its planes in the backward kernel
   float* loss;              // scalar accumulator
 };
 
@@ -63,59 +66,78 @@ __device__ __forceinline__ void hp_store(float* hp, int gtid, const f32x4 (&r)[H
   }
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+typedef _Float16 fh8p __attribute__((ext_vector_type(8)));
+typedef _Float16 fh2p __attribute__((ext_vector_type(2)));
 typedef float f32x2p __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2p __attribute__((ext_vector_type(2)));
 
-constexpr int HPP_ROW = 80;                        // bytes per hp row in a bf16 plane: 32 ci + 16 B pad
+constexpr int HPP_ROW = 80;                        // bytes per hp row in a plane: 32 ci + 16 B pad
 constexpr int HPP_PLANE = HP_ROWS * HPP_ROW;       // 6720
 constexpr int WDP_ROW = 80;                        // bytes per (tap, column) weight row: 32 ci + pad
 constexpr int WDP_PLANE = 4 * 32 * WDP_ROW;        // [dd(4)][n(32)] rows = 10240
-constexpr int FWD_GRP_BYTES = 3 * HPP_PLANE + PC_CELLS * DEC_LD_F * 4 + PC_CELLS * 8 * 4;   // hp planes | dec | dout
 
-__device__ __forceinline__ void split4p(const f32x4& v, u32x2p (&pl)[3]) {
-  f32x2p x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const bf16x2p h01 = __builtin_convertvector(x01, bf16x2p), h23 = __builtin_convertvector(x23, bf16x2p);
-    pl[t] = (u32x2p){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
-    if (t < 2) {
-      x01 = x01 - __builtin_convertvector(h01, f32x2p);
-      x23 = x23 - __builtin_convertvector(h23, f32x2p);
-    }
-  }
+// 4 fp32 -> hi / lo planes of 4 fp16 each: x * scale = hi + lo (round to nearest; 22 significant bits + lo's sign)
+__device__ __forceinline__ void split4p(const f32x4& v, float scale, u32x2p (&pl)[NPLP]) {
+  const f32x2p x01 = (f32x2p){v[0], v[1]} * scale, x23 = (f32x2p){v[2], v[3]} * scale;
+  const fh2p h01 = __builtin_convertvector(x01, fh2p), h23 = __builtin_convertvector(x23, fh2p);
+  const fh2p l01 = __builtin_convertvector(x01 - __builtin_convertvector(h01, f32x2p), fh2p);
+  const fh2p l23 = __builtin_convertvector(x23 - __builtin_convertvector(h23, f32x2p), fh2p);
+  pl[0] = (u32x2p){__builtin_bit_cast(unsigned int, h01), __builtin_bit_cast(unsigned int, h23)};
+  pl[1] = (u32x2p){__builtin_bit_cast(unsigned int, l01), __builtin_bit_cast(unsigned int, l23)};
 }
 
-// hp [81][32] fp32 (registers) -> three bf16 planes in LDS
-__device__ __forceinline__ void hp_store_planes(unsigned char* hpp, int gtid, const f32x4 (&r)[HP_V]) {
+// hp [81][32] fp32 (registers) -> hi / lo planes in LDS
+__device__ __forceinline__ void hp_store_planes(unsigned char* hpp, int gtid, const f32x4 (&r)[HP_V], float scale) {
 #pragma unroll
   for (int c = 0; c < HP_V; ++c) {
     const int id = gtid + 256 * c;
     if (id < C2_POS * 8) {
-      u32x2p pl[3];
-      split4p(r[c], pl);
+      u32x2p pl[NPLP];
+      split4p(r[c], scale, pl);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2p*>(hpp + t * HPP_PLANE + (id >> 3) * HPP_ROW + (id & 7) * 8) = pl[t];
+      for (int t = 0; t < NPLP; ++t) *reinterpret_cast<u32x2p*>(hpp + t * HPP_PLANE + (id >> 3) * HPP_ROW + (id & 7) * 8) = pl[t];
     }
   }
 }
 
-#define PC_SPLIT_MMA(A, B, C)                                          \
-  do {                                                                 \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[0], C, 0, 0, 0); \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[2], C, 0, 0, 0); \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[1], C, 0, 0, 0); \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[0], C, 0, 0, 0); \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[1], C, 0, 0, 0); \
-    C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[0], C, 0, 0, 0); \
+#define PC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define PC_SPLIT_MMA(A, B, C)        \
+  do {                               \
+    C = PC_MFMA(A[1], B[0], C);      \
+    C = PC_MFMA(A[0], B[1], C);      \
+    C = PC_MFMA(A[0], B[0], C);      \
   } while (0)
+
+// max |Wv|, |Wa| over the whole block (the weights' power-of-two scale): call with all 256 threads
+__device__ __forceinline__ float pc_weight_max(const float* __restrict__ Wv, const float* __restrict__ Wa, int A, float* red) {
+  if (threadIdx.x == 0) *red = 0.f;
+  __syncthreads();
+  float m = 0.f;
+  for (int e = threadIdx.x; e < 512; e += 256) m = fmaxf(m, fabsf(Wv[e]));
+  for (int e = threadIdx.x; e < 512 * A; e += 256) m = fmaxf(m, fabsf(Wa[e]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(red), __float_as_uint(m));
+  __syncthreads();
+  return *red;
+}
+
+// LDS of the forward kernel for CO = 1 + A output channels: hp planes | dec | dout | weight planes.  dec holds the
+// pre-activations [400][DS] with an ODD row stride DS >= CO (a thread reads one position's CO floats: odd strides are
+// conflict-free), dout the frame's d_dec [400][CO] dense (it leaves in 16-byte pieces).  At CO <= 7 the workgroup needs
+// <= 53 KB: THREE workgroups per CU (round 2: 76 KB with three bf16 planes and stride-8 rows, two per CU, 55 % of the
+// wave cycles waiting).
+template <int COT> struct FwdLds {
+  static constexpr int DS = COT | 1;
+  static constexpr int DEC = NPLP * HPP_PLANE, DOUT = DEC + PC_CELLS * DS * 4, W = DOUT + PC_CELLS * COT * 4,
+                       BYTES = W + NPLP * WDP_PLANE;
+  static constexpr int WGS = 3 * BYTES <= 160 * 1024 ? 3 : 2;
+};
 
 // deconv of the wave's position tiles (tile ids mt0 and mt0 + 4 when < 7) for ALL parities and channels:
 // column n = par * CO + co (n < 4 * CO <= 32, two 16-wide column tiles); pre-activations + bias -> dec
-template <bool TWO_NT>
+template <bool TWO_NT, int DS>
 __device__ __forceinline__ void deconv_packed(const unsigned char* hpp, const unsigned char* wdp, float* dec, int mt0, int i,
-                                              int q, int CO, const float (&bias)[2]) {
+                                              int q, int CO, const float (&bias)[2], float unscale) {
   constexpr int NTL = TWO_NT ? 2 : 1;
   const int ntiles = (mt0 + 4 < 7) ? 2 : 1;              // wave-uniform
   f32x4 acc[2][NTL];
@@ -131,21 +153,21 @@ __device__ __forceinline__ void deconv_packed(const unsigned char* hpp, const un
 #pragma unroll
   for (int dd = 0; dd < 4; ++dd) {
     const int da = dd >> 1, db = dd & 1;
-    bf16x8 bw[NTL][3];
+    fh8p bw[NTL][NPLP];
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        bw[nt][pl] = *reinterpret_cast<const bf16x8*>(wdp + pl * WDP_PLANE + ((dd * 32 + nt * 16 + i)) * WDP_ROW + 16 * q);
+      for (int pl = 0; pl < NPLP; ++pl)
+        bw[nt][pl] = *reinterpret_cast<const fh8p*>(wdp + pl * WDP_PLANE + ((dd * 32 + nt * 16 + i)) * WDP_ROW + 16 * q);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (t < ntiles) {
         const int y = a[t] - da, x = b[t] - db;
         const int row = (y >= 0 && y < 9 && x >= 0 && x < 9) ? y * 9 + x : C2_POS;
-        bf16x8 av[3];
+        fh8p av[NPLP];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          av[pl] = *reinterpret_cast<const bf16x8*>(hpp + pl * HPP_PLANE + row * HPP_ROW + 16 * q);
+        for (int pl = 0; pl < NPLP; ++pl)
+          av[pl] = *reinterpret_cast<const fh8p*>(hpp + pl * HPP_PLANE + row * HPP_ROW + 16 * q);
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) PC_SPLIT_MMA(av, bw[nt], acc[t][nt]);
       }
@@ -163,28 +185,36 @@ __device__ __forceinline__ void deconv_packed(const unsigned char* hpp, const un
           for (int r = 0; r < 4; ++r) {
             const int m = (mt0 + 4 * t) * 16 + 4 * q + r;
             if (m < 100)
-              dec[((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * DEC_LD_F + co] = acc[t][nt][r] + bias[nt];
+              dec[((2 * (m / 10) + (par >> 1)) * 20 + 2 * (m % 10) + (par & 1)) * DS + co] = acc[t][nt][r] * unscale + bias[nt];
           }
         }
     }
   }
 }
 
-// One frame per 256-thread workgroup at a time, TWO independent workgroups per CU (76.5 KB of LDS each, weight planes
-// included): round 1 ran two frame groups in lock-step inside one 512-thread workgroup (matrix pipe busy 0.18, waves
-// parked 56 %); independent workgroups let one's dueling / loss VALU phase overlap the other's MFMAs.
-__global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_GRP_BYTES + 3 * WDP_PLANE];
+// One frame per 256-thread workgroup at a time, THREE independent workgroups per CU at CO <= 7 (two at CO = 8): one's
+// dueling / loss VALU phase and its global traffic overlap the others' MFMAs.  COT = 1 + A (8: any A <= 7).
+template <int COT>
+__global__ __launch_bounds__(256, FwdLds<COT>::WGS) void pc_deconv_fwd_kernel(PcFwdArgs p) {
+  typedef FwdLds<COT> L;
+  constexpr int DS = L::DS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[L::BYTES];
+  __shared__ float s_red;
   const int gtid = threadIdx.x;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
   unsigned char* hpp = smem;
-  float* dec = reinterpret_cast<float*>(hpp + 3 * HPP_PLANE);
-  float* dout = dec + PC_CELLS * DEC_LD_F;      // staged d_dec of the frame: [400][CO] dense
-  unsigned char* wdp = smem + FWD_GRP_BYTES;
+  float* dec = reinterpret_cast<float*>(smem + L::DEC);
+  float* dout = reinterpret_cast<float*>(smem + L::DOUT);      // staged d_dec of the frame: [400][CO] dense
+  unsigned char* wdp = smem + L::W;
   const int A = p.A, CO = 1 + p.A;
 
-  // weights -> bf16x3 planes [plane][dd][n = par*CO + co (32, zero padded)][ci(32)]: tap dd of parity par is
+  // power-of-two scales (exact): hp from its producer's absmax slot, the weights' maximum reduced here
+  const float S_W = pow2_scale(pc_weight_max(p.Wv, p.Wa, A, &s_red));
+  const float S_HP = pow2_scale(*p.hp_absmax);
+  const float unscale = pow2_inv(S_HP) * pow2_inv(S_W);
+
+  // weights -> hi / lo planes [plane][dd][n = par*CO + co (32, zero padded)][ci(32)]: tap dd of parity par is
   // W[pa + 2da][pb + 2db][co][ci]
   for (int e = threadIdx.x; e < 4 * 32 * 8; e += 256) {      // one f32x4 of ci per item
     const int c4 = e & 7, n = (e >> 3) & 31, dd = e >> 8;
@@ -195,12 +225,12 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = deconv_w(p, ky, kx, co, 4 * c4 + k);
     }
-    u32x2p pl[3];
-    split4p(v, pl);
+    u32x2p pl[NPLP];
+    split4p(v, S_W, pl);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x2p*>(wdp + t * WDP_PLANE + (dd * 32 + n) * WDP_ROW + c4 * 8) = pl[t];
+    for (int t = 0; t < NPLP; ++t) *reinterpret_cast<u32x2p*>(wdp + t * WDP_PLANE + (dd * 32 + n) * WDP_ROW + c4 * 8) = pl[t];
   }
-  for (int e = gtid; e < 3 * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the three hp planes
+  for (int e = gtid; e < NPLP * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the hp planes
     const int t = e / (3 * HPP_ROW / 4), w = e % (3 * HPP_ROW / 4);
     reinterpret_cast<uint32_t*>(hpp + t * HPP_PLANE + C2_POS * HPP_ROW)[w] = 0u;
   }
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
     bias[nt] = (n < 4 * CO) ? (co == 0 ? p.bv[0] : p.ba[co - 1]) : 0.f;
   }
   const bool two_nt = 4 * CO > 16;
-  float loss_acc = 0.f;
+  float loss_acc = 0.f, dd_max = 0.f;
 
   const int stride = gridDim.x;
   f32x4 pre[HP_V];
@@ -220,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
     const int n0 = blockIdx.x;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre);
-      hp_store_planes(hpp, gtid, pre);
+      hp_store_planes(hpp, gtid, pre, S_HP);
     }
   }
   int prev = -1;
@@ -246,8 +276,8 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
       on = p.mask[n] != 0;
     }
     if (valid) {
-      if (two_nt) deconv_packed<true>(hpp, wdp, dec, gw, i, q, CO, bias);
-      else deconv_packed<false>(hpp, wdp, dec, gw, i, q, CO, bias);
+      if (two_nt) deconv_packed<true, DS>(hpp, wdp, dec, gw, i, q, CO, bias, unscale);
+      else deconv_packed<false, DS>(hpp, wdp, dec, gw, i, q, CO, bias, unscale);
     }
     __syncthreads();  // [S1] dec complete; hp free; dout drained
     if (valid) {
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
       for (int pi = 0; pi < 2; ++pi) {
         const int pos = gtid + 256 * pi;
         if (pos >= PC_CELLS) break;
-        const float* d = dec + pos * DEC_LD_F;
+        const float* d = dec + pos * DS;
         const float vpre = d[0];
         const float V = fmaxf(vpre, 0.f);
         float adv[8], mean = 0.f;
@@ -274,12 +304,13 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
           if (on) loss_acc += 0.5f * p.lambda * diff * diff;
           float* o = dout + pos * CO;
           o[0] = vpre > 0.f ? dq : 0.f;
+          dd_max = fmaxf(dd_max, fabsf(dq));          // |d_dec| <= |dq| (the advantage factors are within [-1, 1])
           for (int k = 0; k < A; ++k)
             o[1 + k] = d[1 + k] > 0.f ? dq * (((k == act) ? 1.f : 0.f) - 1.f / (float)A) : 0.f;
         }
       }
     }
-    if (has_next) hp_store_planes(hpp, gtid, pre);
+    if (has_next) hp_store_planes(hpp, gtid, pre, S_HP);
     prev = valid ? n : -1;
   }
   __syncthreads();
@@ -287,23 +318,34 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_fwd_kernel(PcFwdArgs p) {
     f32x4* dst = reinterpret_cast<f32x4*>(p.d_dec + (size_t)prev * PC_CELLS * CO);
     for (int id = gtid; id < PC_CELLS * CO / 4; id += 256) dst[id] = reinterpret_cast<const f32x4*>(dout)[id];
   }
-  if (p.loss) {
+  // one atomic per workgroup and output (block-uniform pointers): the workgroups of a launch end within microseconds of
+  // each other, and same-address atomics serialise
+  {
+    __shared__ float wsum[4], wmx[4];
     loss_acc = wave_sum(loss_acc);
-    if (lane == 0) atomicAdd(p.loss, loss_acc * p.grad_scale);
+    dd_max = wave_max(dd_max);
+    if (lane == 0) { wsum[gw] = loss_acc; wmx[gw] = dd_max; }
+    __syncthreads();
+    if (gw == 0) {
+      if (p.loss && lane == 0) atomicAdd(p.loss, (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]) * p.grad_scale);
+      if (p.ddec_absmax) absmax_commit(p.ddec_absmax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));   // bound of max |d_dec|
+    }
   }
 }
 
 struct PcBwdArgs {
   int N, A;
   const float* hp;          // [N][2592] relu(pc_fc1) (forward activation)
+  const float* hp_absmax;   // absmax slot covering hp
   const float* d_dec;       // [N][400][1+A]
+  const float* ddec_absmax; // absmax slot covering d_dec (committed by the forward kernel)
   const float* Wv; const float* Wa;
   float* d_hp;              // [N][2592] gradient wrt pc_fc1 PRE-activation (relu mask applied)
   float* dWv; float* dbv; float* dWa; float* dba;
   float* dhp_absmax;        // nullable absmax slot (common.h): max |d_hp|, the A scale of the pc_fc1 dgrad GEMM
 };
 
-// Backward on the split-operand scheme of the forward (three bf16 planes per operand, six term-pair MFMAs):
+// Backward on the split-operand scheme of the forward (fp16 hi + lo planes per operand, three term-pair MFMAs):
 //   dgrad  d_hp[pos][ci] = sum_{ky,kx,co} d_dec[2y+ky][2x+kx][co] W[ky][kx][co][ci]
 //          per ky one 32-deep step: k = (kx, co) is 64 contiguous bytes of the d_dec planes ([400 pos][8 co] bf16);
 //   wgrad  dW[(ky,kx,co)][ci] += sum_pos d_dec[2y+ky][2x+kx][co] hp[pos][ci]
@@ -315,58 +357,64 @@ typedef short s16x8p __attribute__((ext_vector_type(8)));
 constexpr int DDP_ROW = 16;                          // bytes per output position in a d_dec plane (8 co bf16)
 constexpr int DDP_PLANE = (PC_CELLS + 4) * DDP_ROW;  // + 4 zero rows (positions past the 81 of the last k step)
 constexpr int WBP_PLANE = 4 * 32 * WDP_ROW;          // [ky][ci(32)] rows of 32 (kx,co) bf16 + pad = 10240
-constexpr int BWD_GRP_BYTES = 3 * HPP_PLANE + 3 * DDP_PLANE + F2_DIM * 4;   // hp planes | d_dec planes | d_hp staging
+constexpr int BWD_GRP_BYTES = NPLP * HPP_PLANE + NPLP * DDP_PLANE + F2_DIM * 4;   // hp planes | d_dec planes | d_hp staging
 
-__device__ __forceinline__ bf16x8 tr_pair_p(const unsigned char* a0, const unsigned char* a1) {
+__device__ __forceinline__ fh8p tr_pair_p(const unsigned char* a0, const unsigned char* a1) {
   typedef s16x4p __attribute__((address_space(3))) * lds_p;
   const s16x4p lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a0));
   const s16x4p hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a1));
   const s16x8p v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
+  return __builtin_bit_cast(fh8p, v);
 }
 
-// one fp32 value -> its three bf16 terms (round to nearest, residuals exact)
-__device__ __forceinline__ void split1p(float x, unsigned short (&t)[3]) {
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const __bf16 h = (__bf16)x;
-    t[k] = __builtin_bit_cast(unsigned short, h);
-    x -= (float)h;
-  }
+// one fp32 value -> its fp16 hi / lo terms under `scale`
+__device__ __forceinline__ void split1p(float x, float scale, unsigned short (&t)[NPLP]) {
+  x *= scale;
+  const _Float16 h = (_Float16)x;
+  const _Float16 l = (_Float16)(x - (float)h);
+  t[0] = __builtin_bit_cast(unsigned short, h);
+  t[1] = __builtin_bit_cast(unsigned short, l);
 }
 
-// one frame per 256-thread workgroup at a time, two independent workgroups per CU (80.6 KB of LDS each), like the forward
+// one frame per 256-thread workgroup at a time, two independent workgroups per CU (57 KB of LDS each)
 __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_GRP_BYTES + 3 * WBP_PLANE];
-  static_assert(2 * (BWD_GRP_BYTES + 3 * WBP_PLANE) <= 160 * 1024, "two workgroups must fit one CU's LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_GRP_BYTES + NPLP * WBP_PLANE];
+  __shared__ float s_red;
+  static_assert(2 * (BWD_GRP_BYTES + NPLP * WBP_PLANE) <= 160 * 1024, "two workgroups must fit one CU's LDS");
   const int gtid = threadIdx.x;
   const int lane = threadIdx.x & 63, gw = gtid >> 6;
   const int i = lane & 15, q = lane >> 4;
   unsigned char* hpp = smem;
-  unsigned char* ddp = hpp + 3 * HPP_PLANE;
-  float* dhs = reinterpret_cast<float*>(ddp + 3 * DDP_PLANE);      // staged d_hp of the frame: [81][32] dense
+  unsigned char* ddp = hpp + NPLP * HPP_PLANE;
+  float* dhs = reinterpret_cast<float*>(ddp + NPLP * DDP_PLANE);      // staged d_hp of the frame: [81][32] dense
   unsigned char* wbp = smem + BWD_GRP_BYTES;
   const int A = p.A, CO = 1 + p.A;
 
-  // weights -> bf16x3 planes [plane][ky][ci(32)][k = kx*8 + co (32, co >= CO zero)]
+  // power-of-two scales (exact): hp / d_dec from their absmax slots, the weights' maximum reduced here
+  const float S_W = pow2_scale(pc_weight_max(p.Wv, p.Wa, A, &s_red));
+  const float S_HP = pow2_scale(*p.hp_absmax), S_DD = pow2_scale(*p.ddec_absmax);
+  const float un_dgrad = pow2_inv(S_DD) * pow2_inv(S_W);       // d_hp = d_dec . W
+  const float un_wgrad = pow2_inv(S_DD) * pow2_inv(S_HP);      // dW   = d_dec^T . hp
+
+  // weights -> hi / lo planes [plane][ky][ci(32)][k = kx*8 + co (32, co >= CO zero)]
   for (int e = threadIdx.x; e < 4 * 32 * 32; e += 256) {
     const int k = e & 31, ci = (e >> 5) & 31, ky = e >> 10;
     const int kx = k >> 3, co = k & 7;
     float v = 0.f;
     if (co == 0) v = p.Wv[(ky * 4 + kx) * 32 + ci];
     else if (co <= A) v = p.Wa[((ky * 4 + kx) * A + (co - 1)) * 32 + ci];
-    unsigned short t[3];
-    split1p(v, t);
+    unsigned short t[NPLP];
+    split1p(v, S_W, t);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPLP; ++pl)
       reinterpret_cast<unsigned short*>(wbp + pl * WBP_PLANE + (ky * 32 + ci) * WDP_ROW)[k] = t[pl];
   }
-  for (int e = gtid; e < 3 * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the three hp planes
+  for (int e = gtid; e < NPLP * 3 * HPP_ROW / 4; e += 256) {      // zero rows 81..83 of the hp planes
     const int t = e / (3 * HPP_ROW / 4), w = e % (3 * HPP_ROW / 4);
     reinterpret_cast<uint32_t*>(hpp + t * HPP_PLANE + C2_POS * HPP_ROW)[w] = 0u;
   }
   // d_dec planes: the co >= CO padding columns and the 4 extra rows stay zero (never rewritten)
-  for (int e = gtid; e < 3 * DDP_PLANE / 4; e += 256) reinterpret_cast<uint32_t*>(ddp)[e] = 0u;
+  for (int e = gtid; e < NPLP * DDP_PLANE / 4; e += 256) reinterpret_cast<uint32_t*>(ddp)[e] = 0u;
 
   f32x4 aw[2][2];          // dW tiles: ky = gw, kxh = 0..1 (kx = 2kxh + (row>>3), co = row&7), nt = 0..1
 #pragma unroll
@@ -404,11 +452,11 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     for (int h = 0; h < 2; ++h) {
       const int pos = gtid + 256 * h;
       if (pos < PC_CELLS) {
-        u32x2p lo[3], hi[3];
-        split4p((f32x4){pre_dd[h][0], pre_dd[h][1], pre_dd[h][2], pre_dd[h][3]}, lo);
-        split4p((f32x4){pre_dd[h][4], pre_dd[h][5], pre_dd[h][6], pre_dd[h][7]}, hi);
+        u32x2p lo[NPLP], hi[NPLP];
+        split4p((f32x4){pre_dd[h][0], pre_dd[h][1], pre_dd[h][2], pre_dd[h][3]}, S_DD, lo);
+        split4p((f32x4){pre_dd[h][4], pre_dd[h][5], pre_dd[h][6], pre_dd[h][7]}, S_DD, hi);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPLP; ++pl) {
           typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
           *reinterpret_cast<u32x4p*>(ddp + pl * DDP_PLANE + pos * DDP_ROW) = (u32x4p){lo[pl][0], lo[pl][1], hi[pl][0], hi[pl][1]};
         }
@@ -423,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     const int n0 = blockIdx.x;
     if (n0 < p.N) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
-      hp_store_planes(hpp, gtid, pre_hp);
+      hp_store_planes(hpp, gtid, pre_hp, S_HP);
       load_dd(n0);
       stage_dd();
     }
@@ -451,16 +499,16 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
         }
 #pragma unroll
         for (int ky = 0; ky < 4; ++ky) {
-          bf16x8 bw[3];
+          fh8p bw[NPLP];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            bw[pl] = *reinterpret_cast<const bf16x8*>(wbp + pl * WBP_PLANE + (ky * 32 + nt * 16 + i) * WDP_ROW + 16 * q);
+          for (int pl = 0; pl < NPLP; ++pl)
+            bw[pl] = *reinterpret_cast<const fh8p*>(wbp + pl * WBP_PLANE + (ky * 32 + nt * 16 + i) * WDP_ROW + 16 * q);
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) {
-            bf16x8 av[3];
+            fh8p av[NPLP];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-              av[pl] = *reinterpret_cast<const bf16x8*>(ddp + pl * DDP_PLANE + abase[jj] + ky * 20 * DDP_ROW);
+            for (int pl = 0; pl < NPLP; ++pl)
+              av[pl] = *reinterpret_cast<const fh8p*>(ddp + pl * DDP_PLANE + abase[jj] + ky * 20 * DDP_ROW);
             PC_SPLIT_MMA(av, bw, acc[jj]);
           }
         }
@@ -471,9 +519,9 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
             const int pos = ((gw >> 1) + 2 * jj) * 16 + 4 * q + r;
             if (pos < C2_POS) {
               const int ci = nt * 16 + i;
-              // relu mask of pc_fc1: hp > 0 <=> its leading bf16 term > 0
+              // relu mask of pc_fc1: hp > 0 <=> its hi term > 0
               const unsigned short h0 = reinterpret_cast<const unsigned short*>(hpp + pos * HPP_ROW)[ci];
-              dhs[pos * 32 + ci] = (h0 != 0 && !(h0 & 0x8000)) ? acc[jj][r] : 0.f;
+              dhs[pos * 32 + ci] = (h0 != 0 && !(h0 & 0x8000)) ? acc[jj][r] * un_dgrad : 0.f;
             }
           }
       }
@@ -483,19 +531,19 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
         const int p0 = 32 * ks + 8 * q + qq, p1 = p0 + 4;
         const unsigned char* b0 = hpp + min(p0, C2_POS) * HPP_ROW + 8 * pp;
         const unsigned char* b1 = hpp + min(p1, C2_POS) * HPP_ROW + 8 * pp;
-        bf16x8 bf[2][3];
+        fh8p bf[2][NPLP];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) bf[t][pl] = tr_pair_p(b0 + pl * HPP_PLANE + 32 * t, b1 + pl * HPP_PLANE + 32 * t);
+          for (int pl = 0; pl < NPLP; ++pl) bf[t][pl] = tr_pair_p(b0 + pl * HPP_PLANE + 32 * t, b1 + pl * HPP_PLANE + 32 * t);
         // d_dec block row of position p: output rows (2y+ky, 2x + 2kxh .. +1) x 8 co = 32 contiguous bytes
         const int r0 = p0 < C2_POS ? (2 * (p0 / 9) + gw) * 20 + 2 * (p0 % 9) : PC_CELLS;
         const int r1 = p1 < C2_POS ? (2 * (p1 / 9) + gw) * 20 + 2 * (p1 % 9) : PC_CELLS;
 #pragma unroll
         for (int kxh = 0; kxh < 2; ++kxh) {
-          bf16x8 af[3];
+          fh8p af[NPLP];
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < NPLP; ++pl)
             af[pl] = tr_pair_p(ddp + pl * DDP_PLANE + (r0 + 2 * kxh) * DDP_ROW + 8 * pp,
                                ddp + pl * DDP_PLANE + (r1 + 2 * kxh) * DDP_ROW + 8 * pp);
           PC_SPLIT_MMA(af, bf[0], aw[kxh][0]);
@@ -513,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       }
     }
     if (has_next) {
-      hp_store_planes(hpp, gtid, pre_hp);
+      hp_store_planes(hpp, gtid, pre_hp, S_HP);
       stage_dd();
     }
   }
@@ -526,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       for (int r = 0; r < 4; ++r) {
         int row = 4 * q + r;                 // row in the 16-row tile: kx = 2kxh + (row>>3), co = row&7
         int kx = 2 * kxh + (row >> 3), co = row & 7, ci = t * 16 + i;
-        float v = aw[kxh][t][r];
+        float v = aw[kxh][t][r] * un_wgrad;
         if (co == 0) atomicAdd(p.dWv + (gw * 4 + kx) * 32 + ci, v);
         else if (co <= A) atomicAdd(p.dWa + ((gw * 4 + kx) * A + (co - 1)) * 32 + ci, v);
       }
@@ -538,32 +586,50 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       else atomicAdd(p.dba + (k - 1), v);
     }
   }
-  absmax_commit(p.dhp_absmax, dhp_max);
+  {                                          // one commit per workgroup
+    __shared__ float wmx[4];
+    dhp_max = wave_max(dhp_max);
+    if (lane == 0) wmx[gw] = dhp_max;
+    __syncthreads();
+    if (gw == 0) absmax_commit(p.dhp_absmax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
+  }
 }
 
 }  // namespace
 
 extern "C" {
 
-int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* Wv, const float* bv, const float* Wa,
-                         const float* ba, float* qmax, const int* action, const float* target, const int* mask,
-                         float lambda, float grad_scale, float* d_dec, float* loss, void* stream) {
-  if (N <= 0 || A <= 0 || A > 7 || !hp || !Wv || !bv || !Wa || !ba) return UNREAL_EINVAL;
+int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* hp_absmax, const float* Wv, const float* bv,
+                         const float* Wa, const float* ba, float* qmax, const int* action, const float* target,
+                         const int* mask, float lambda, float grad_scale, float* d_dec, float* ddec_absmax, float* loss,
+                         void* stream) {
+  if (N <= 0 || A <= 0 || A > 7 || !hp || !hp_absmax || !Wv || !bv || !Wa || !ba) return UNREAL_EINVAL;
   if (!qmax && !d_dec) return UNREAL_EINVAL;
   if (d_dec && (!action || !target || !mask || !loss)) return UNREAL_EINVAL;
   if ((((uintptr_t)hp) | ((uintptr_t)d_dec)) & 15) return UNREAL_EINVAL;
-  PcFwdArgs p{N, A, hp, Wv, bv, Wa, ba, qmax, action, target, mask, lambda, grad_scale, d_dec, d_dec ? loss : nullptr};
-  int blocks = min(N, 512);
-  hipLaunchKernelGGL(pc_deconv_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  PcFwdArgs p{N, A, hp, hp_absmax, Wv, bv, Wa, ba, qmax, action, target, mask, lambda, grad_scale, d_dec,
+              d_dec ? ddec_absmax : nullptr, d_dec ? loss : nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  // one frame per workgroup at a time; as many workgroups as fit the chip (3 per CU at 1 + A <= 7 channels)
+#define PC_FWD(COT) hipLaunchKernelGGL(pc_deconv_fwd_kernel<COT>, dim3(min(N, 256 * FwdLds<COT>::WGS)), dim3(256), 0, st, p)
+  switch (1 + A) {
+    case 4: PC_FWD(4); break;      // indoor (A = 3)
+    case 5: PC_FWD(5); break;      // maze (A = 4)
+    case 7: PC_FWD(7); break;      // lab (A = 6)
+    default: PC_FWD(8); break;
+  }
+#undef PC_FWD
   return unreal_launch_status();
 }
 
-int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* d_dec, const float* Wv, const float* Wa,
-                         float* d_hp, float* dhp_absmax, float* dWv, float* dbv, float* dWa, float* dba, void* stream) {
-  if (N <= 0 || A <= 0 || A > 7 || !hp || !d_dec || !Wv || !Wa || !d_hp || !dWv || !dbv || !dWa || !dba)
+int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* hp_absmax, const float* d_dec, const float* ddec_absmax,
+                         const float* Wv, const float* Wa, float* d_hp, float* dhp_absmax, float* dWv, float* dbv, float* dWa,
+                         float* dba, void* stream) {
+  if (N <= 0 || A <= 0 || A > 7 || !hp || !hp_absmax || !d_dec || !ddec_absmax || !Wv || !Wa || !d_hp || !dWv || !dbv ||
+      !dWa || !dba)
     return UNREAL_EINVAL;
   if ((((uintptr_t)hp) | ((uintptr_t)d_dec) | ((uintptr_t)d_hp)) & 15) return UNREAL_EINVAL;
-  PcBwdArgs p{N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_absmax};
+  PcBwdArgs p{N, A, hp, hp_absmax, d_dec, ddec_absmax, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_absmax};
   int blocks = min(N, 512);
   hipLaunchKernelGGL(pc_deconv_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();

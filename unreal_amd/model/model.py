@@ -495,16 +495,17 @@ class UnrealModel(object):
         p = self.p
         ops.linear_small_fwd(rows, 256, 1, feat, ld, p["W_base_fc_v"], p["b_base_fc_v"], v_out, 1)
 
-    def pc_head_forward(self, rows, feat, ld, hp, ws=None):
+    def pc_head_forward(self, rows, feat, ld, hp, ws=None, hp_max=None):
         """hp = relu(feat @ W_pc_fc1 + b).  `ws`: the workspace the features live in (its absmax slot of the fc rows is the
-        A scale in FF mode; LSTM outputs are bounded by 1: a slot holding 1.0)."""
+        A scale in FF mode; LSTM outputs are bounded by 1: a slot holding 1.0).  `hp_max`: absmax slot that receives
+        max hp -- the scale of hp's fp16 planes in the deconvolution kernels."""
         p = self.p
         if self._use_lstm:
             a_max = self._one
         else:
             a_max = ws.s_x if ws is not None and getattr(ws, "s_x", None) is not None else None
         ops.gemm_split_nt(rows, 2592, 256, feat, ld, self.shadow["pc_fc1_fwd"], hp, 2592, bias=p["b_pc_fc1"],
-                          flags=ops.GEMM_RELU, a_max=a_max)
+                          flags=ops.GEMM_RELU, a_max=a_max, c_max=hp_max)
 
     # -- reference batch-1 runners (model.py:630-728) ---------------------------------------------------
     def _b1_ws(self):

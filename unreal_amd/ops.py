@@ -596,22 +596,30 @@ def relu_mask(rows, cols, d, ldd, src, lds):
 
 
 def pc_deconv_fwd(N, A, hp, Wv, bv, Wa, ba, qmax=None, action=None, target=None, mask=None, lam=0.0,
-                  grad_scale=1.0, d_dec=None, loss=None):
+                  grad_scale=1.0, d_dec=None, loss=None, hp_max=None, ddec_max=None):
+    """hp_max: absmax slot covering hp (None: reduced here with one extra launch); ddec_max: slot that receives an upper
+    bound of max |d_dec| (training mode; what pc_deconv_bwd scales its d_dec planes by)."""
     _chk(hp, "f32", N * F2_DIM); _chk(Wv, "f32", 512); _chk(bv, "f32", 1); _chk(Wa, "f32", 512 * A); _chk(ba, "f32", A)
     _chk(qmax, "f32", N * PC_CELLS, optional=True); _chk(action, "i32", N, optional=True)
     _chk(target, "f32", N * PC_CELLS, optional=True); _chk(mask, "i32", N, optional=True)
     _chk(d_dec, "f32", N * PC_CELLS * (1 + A), optional=True); _chk(loss, "f32", 1, optional=True)
-    _call("unreal_pc_deconv_fwd", N, A, ptr(hp), ptr(Wv), ptr(bv), ptr(Wa), ptr(ba), ptr(qmax), ptr(action),
-          ptr(target), ptr(mask), float(lam), float(grad_scale), ptr(d_dec), ptr(loss))
+    _chk(hp_max, "f32", 1, "hp_max", optional=True); _chk(ddec_max, "f32", 1, "ddec_max", optional=True)
+    hp_max = _absmax_of(hp, N, F2_DIM, F2_DIM, hp_max)
+    _call("unreal_pc_deconv_fwd", N, A, ptr(hp), ptr(hp_max), ptr(Wv), ptr(bv), ptr(Wa), ptr(ba), ptr(qmax), ptr(action),
+          ptr(target), ptr(mask), float(lam), float(grad_scale), ptr(d_dec), ptr(ddec_max), ptr(loss))
 
 
-def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_max=None):
+def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_max=None, hp_max=None, ddec_max=None):
+    """hp_max / ddec_max: absmax slots covering hp / d_dec (None: reduced here with one extra launch each)."""
     _chk(hp, "f32", N * F2_DIM); _chk(d_dec, "f32", N * PC_CELLS * (1 + A)); _chk(Wv, "f32", 512)
     _chk(Wa, "f32", 512 * A); _chk(d_hp, "f32", N * F2_DIM); _chk(dWv, "f32", 512); _chk(dbv, "f32", 1)
     _chk(dWa, "f32", 512 * A); _chk(dba, "f32", A)
     _chk(dhp_max, "f32", 1, "dhp_max", optional=True)
-    _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(d_dec), ptr(Wv), ptr(Wa), ptr(d_hp), ptr(dhp_max), ptr(dWv), ptr(dbv),
-          ptr(dWa), ptr(dba))
+    _chk(hp_max, "f32", 1, "hp_max", optional=True); _chk(ddec_max, "f32", 1, "ddec_max", optional=True)
+    hp_max = _absmax_of(hp, N, F2_DIM, F2_DIM, hp_max)
+    ddec_max = _absmax_of(d_dec, N, PC_CELLS * (1 + A), PC_CELLS * (1 + A), ddec_max)
+    _call("unreal_pc_deconv_bwd", N, A, ptr(hp), ptr(hp_max), ptr(d_dec), ptr(ddec_max), ptr(Wv), ptr(Wa), ptr(d_hp),
+          ptr(dhp_max), ptr(dWv), ptr(dbv), ptr(dWa), ptr(dba))
 
 
 def axpy(alpha, x, y):

@@ -454,21 +454,24 @@ class Trainer(object):
         ws = self.aux_ws                              # (allocates the per-branch workspace on first use)
         gws.ensure_pc(rows, A)
         feat, ld = self._sample_sequence()
-        net.pc_head_forward(B, feat, ld, self.boot_hp, ws=self.boot_ws)
+        s_bhp = net.new_slot()             # max of the bootstrap frames' hp: committed by the pc_fc1 GEMM
+        net.pc_head_forward(B, feat, ld, self.boot_hp, ws=self.boot_ws, hp_max=s_bhp)
         ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
-                          p["b_pc_deconv_a"], qmax=self.boot_qmax)
+                          p["b_pc_deconv_a"], qmax=self.boot_qmax, hp_max=s_bhp)
         ops.pc_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.boot_qmax, self.gamma_pc, gws.pc_R)
         feat, ld = self._aux_forward()
-        net.pc_head_forward(rows, feat, ld, gws.hp, ws=self.aux_ws)
+        s_hp, s_dd = net.new_slot(), net.new_slot()      # max hp (pc_fc1 GEMM) / bound of max |d_dec| (deconv forward)
+        net.pc_head_forward(rows, feat, ld, gws.hp, ws=self.aux_ws, hp_max=s_hp)
         ops.gather_i32(self.ring.r_action, self.aux_ws.frame_idx[:rows], self.seq_act)
         ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask,
                           lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
-                          loss=self.losses[3:4])
+                          loss=self.losses[3:4], hp_max=s_hp, ddec_max=s_dd)
         d_hp = gws.d_f2
         s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
         ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp)
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
+                          hp_max=s_hp, ddec_max=s_dd)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592,
                               splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
@@ -515,9 +518,10 @@ class Trainer(object):
             bw.c0.zero_()
             bw.h0.zero_()
         feat, ld = net.trunk_forward(self.ring, bw, 1, 2 * B, lar_from_ring=True, save_c1=False)
-        net.pc_head_forward(B, feat, 2 * ld, self.boot_hp, ws=self.boot2_ws)
+        s_bhp = net.new_slot()             # max of the bootstrap frames' hp: committed by the pc_fc1 GEMM
+        net.pc_head_forward(B, feat, 2 * ld, self.boot_hp, ws=self.boot2_ws, hp_max=s_bhp)
         ops.pc_deconv_fwd(B, A, self.boot_hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
-                          p["b_pc_deconv_a"], qmax=self.boot_qmax)
+                          p["b_pc_deconv_a"], qmax=self.boot_qmax, hp_max=s_bhp)
         ops.pc_returns(self.ring, L, self.seq_idx2[0], self.seq_len2[0], self.boot_qmax, self.gamma_pc, gws.pc_R)
         net.value_forward(B, feat[ld:], 2 * ld, self.aux_boot_v)
         ops.vr_returns(self.ring, L, self.seq_idx2[1], self.seq_len2[1], self.aux_boot_v, self.gamma, self.aux_R)
@@ -530,16 +534,18 @@ class Trainer(object):
         feat, ld = net.trunk_forward(self.ring, ws, Ta, 2 * B, lar_from_ring=True, save_c1=True)
         d_feat = gws.d_feat
         # pixel-control head on the even rows
-        net.pc_head_forward(rows, feat, 2 * ld, gws.hp, ws=self.aux2_ws)
+        s_hp, s_dd = net.new_slot(), net.new_slot()      # max hp (pc_fc1 GEMM) / bound of max |d_dec| (deconv forward)
+        net.pc_head_forward(rows, feat, 2 * ld, gws.hp, ws=self.aux2_ws, hp_max=s_hp)
         ops.gather_i32(self.ring.r_action, self.seq_idx2[0][:rows], self.seq_act)
         ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
                           p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask2[0],
                           lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
-                          loss=self.losses[3:4])
+                          loss=self.losses[3:4], hp_max=s_hp, ddec_max=s_dd)
         d_hp = gws.d_hp
         s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
         ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp)
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
+                          hp_max=s_hp, ddec_max=s_dd)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, 2 * ld, d_hp, 2592, g["W_pc_fc1"], 2592,
                           splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
