@@ -11,9 +11,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = {"base": [], "deep128": ["-DSPLIT_NT_DEEP128=1"],
-            # timing only (wrong results): no split + LDS store after the first tile / no global loads in the K loop
-            "nosplit": ["-DSPLIT_ABLATE=2"], "noload": ["-DSPLIT_ABLATE=1"], "nosplit_noload": ["-DSPLIT_ABLATE=3"]}
+VARIANTS = {"base": [], "deep128": ["-DSPLIT_NT_DEEP128=1"]}
+# earlier rounds of this script (results in profiles/r03_gemm_nt_ablate.log): timing-only ablations "nosplit" / "noload" /
+# "nosplit_noload" = -DSPLIT_ABLATE=2 / 1 / 3 (pass them as name=-DFLAG on the command line); the direct-store epilogue
+# and the 128 x 256 tile variants were removed from the kernel after they lost
 for a in sys.argv[1:]:             # extra variants: name=-DX=1,-DY=2
     if "=" in a and not a.startswith("--"):
         k, v = a.split("=", 1)
