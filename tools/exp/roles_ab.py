@@ -85,7 +85,7 @@ if "--stamps" in sys.argv:
         lib.exp_read_rstamps(buf, 0)
         iters = (N - 3 + 255) // 256
         print("variant %d: cycles per frame (workgroup 3, %d frames)" % (var, iters))
-        for w in (0, 3, 4, 7):
+        for w in range(8):
             tot = sum(buf[w * 16 + k] for k in range(16))
             print("  wave %d total %.0f: " % (w, tot / iters) + ", ".join("%s %.0f" % (names[k], buf[w * 16 + k] / iters) for k in range(12) if buf[w * 16 + k]))
 sys.exit(0 if ok else 1)

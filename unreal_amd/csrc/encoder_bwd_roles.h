@@ -620,25 +620,42 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_roles_kernel(int N, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * (NT3 * tset + u) + 4 * q + r) * 16 + i, scale * (aw1[u][r] * INV_D1));
   }
-  if (consumer || P2SPLIT) {       // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
+  // bias gradients: ONE atomic per workgroup and channel (the 256 workgroups end together: 2,048 / 1,024 same-address
+  // atomics per channel from per-wave flushes serialised into ~25 us per launch).  Partials meet in LDS -- the planes are
+  // dead once every wave has left phase 3 of the last frame (first barrier).
+  float v1[4], v2[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = adb1[e];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      if (i == 0) atomicAdd(db1 + 4 * q + e, v);
-    }
+  for (int e = 0; e < 4; ++e) {        // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
+    float v = (consumer || P2SPLIT) ? adb1[e] : 0.f;
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v1[e] = v;
+    float u = consumer ? 0.f : adb2[e];  // db2: producer threads with equal (t256 % 8) own the same 4 columns
+    u += __shfl_xor(u, 8, 64);
+    u += __shfl_xor(u, 16, 64);
+    u += __shfl_xor(u, 32, 64);
+    v2[e] = u;
   }
-  if (!consumer) {                 // db2: threads with equal (t256 % 8) own the same 4 columns
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                 // [8 waves][16] db1 | [4 producers][32] db2
+  if (i == 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = adb2[e];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lane < 8) atomicAdd(db2 + lane * 4 + e, v);
-    }
+    for (int e = 0; e < 4; ++e) red[wv * 16 + 4 * q + e] = v1[e];
+  }
+  if (!consumer && lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[128 + (wv - 4) * 32 + lane * 4 + e] = v2[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sum += red[w * 16 + tid];
+    atomicAdd(db1 + tid, sum);
+  } else if (tid >= 64 && tid < 96) {
+    const int c = tid - 64;
+    atomicAdd(db2 + c, (red[128 + c] + red[160 + c]) + (red[192 + c] + red[224 + c]));
   }
 }

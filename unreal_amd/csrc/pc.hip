@@ -578,19 +578,21 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
         if (co == 0) atomicAdd(p.dWv + (gw * 4 + kx) * 32 + ci, v);
         else if (co <= A) atomicAdd(p.dWa + ((gw * 4 + kx) * A + (co - 1)) * 32 + ci, v);
       }
+  {                                          // one atomic / commit per workgroup for the bias gradients and max |d_hp|
+    __shared__ float wsum[4][8], wmx[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float v = wave_sum(adbk[k]);
-    if (lane == 0 && k < CO) {
-      if (k == 0) atomicAdd(p.dbv, v);
-      else atomicAdd(p.dba + (k - 1), v);
+    for (int k = 0; k < 8; ++k) {
+      const float v = wave_sum(adbk[k]);
+      if (lane == 0) wsum[gw][k] = v;
     }
-  }
-  {                                          // one commit per workgroup
-    __shared__ float wmx[4];
     dhp_max = wave_max(dhp_max);
     if (lane == 0) wmx[gw] = dhp_max;
     __syncthreads();
+    if (gtid < CO) {
+      const float v = ((wsum[0][gtid] + wsum[1][gtid]) + wsum[2][gtid]) + wsum[3][gtid];
+      if (gtid == 0) atomicAdd(p.dbv, v);
+      else atomicAdd(p.dba + (gtid - 1), v);
+    }
     if (gw == 0) absmax_commit(p.dhp_absmax, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
   }
 }
