@@ -82,8 +82,12 @@ __device__ __forceinline__ void render_walls(uint8_t* dst, const uint4* img) {
 __device__ __forceinline__ void render_agent(uint8_t* dst, int ax, int ay) {
   if (threadIdx.x < 12 * 9) {
     const int r = threadIdx.x / 9, w = threadIdx.x % 9;            // dword w of the 36-byte run: bytes 4w..4w+3
-    const uint32_t pat[3] = {0x00000100u, 0x01000001u, 0x00010000u};   // (0,1,0) repeated; byte 4w is channel w mod 3
-    reinterpret_cast<uint32_t*>(dst + (12 * ay + r) * FRAME_ROW_BYTES + 36 * ax)[w] = pat[w % 3];
+    // (0,1,0) repeated; byte 4w is channel w mod 3.  Selects, not a table: the compiler put `pat[3]` into constant memory, and
+    // the global load it then needed in here came with s_waitcnt vmcnt(0) -- which also waits for the wave's wall stores
+    // of this frame: a memory round trip per actor, and the next actor's barrier made the whole workgroup wait for it
+    const int ph = w % 3;
+    const uint32_t pat = ph == 0 ? 0x00000100u : (ph == 1 ? 0x01000001u : 0x00010000u);
+    reinterpret_cast<uint32_t*>(dst + (12 * ay + r) * FRAME_ROW_BYTES + 36 * ax)[w] = pat;
   }
 }
 
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   // per-actor loop, each actor would start with two dependent global round trips (state, then the previous slot's terminal
   // flag) that nothing overlaps -- 8 actors x ~2 us of a 38 us launch
   __shared__ int s_flag[kActorsPerGroup], s_x[kActorsPerGroup], s_y[kActorsPerGroup], s_a[kActorsPerGroup],
-      s_cnt[kActorsPerGroup], s_la[kActorsPerGroup], s_prev[kActorsPerGroup];
+      s_cnt[kActorsPerGroup], s_la[kActorsPerGroup], s_prev[kActorsPerGroup], s_ns[kActorsPerGroup];
   __shared__ float s_lr[kActorsPerGroup], s_ep[kActorsPerGroup];
   if (threadIdx.x < kActorsPerGroup) {
     const int k = threadIdx.x, b = blockIdx.x * kActorsPerGroup + k;
@@ -145,6 +149,8 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
       s_la[k] = p.last_action[b];
       s_lr[k] = p.last_reward[b];
       s_ep[k] = p.track_score ? p.episode_reward[b] : 0.f;
+      s_ns[k] = p.active_rw ? p.n_steps[b] : 0;      // (read here: a load inside the actor loop stalls thread 0's wave -- and,
+                                                     // through the loop's barrier, the workgroup -- for a memory round trip per actor)
       s_prev[k] = cnt > 0 ? p.r_terminal[(size_t)b * p.H1 + (cnt - 1) % p.H1] : 0;
     }
   }
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
         p.episode_reward[b] = ep;
       }
       if (p.active_rw) {
-        p.n_steps[b] += 1;
+        p.n_steps[b] = s_ns[k] + 1;
         if (terminal) {
           p.active_rw[b] = 0;
           p.terminal_end[b] = 1;
