@@ -130,16 +130,20 @@ struct StepArgs {
   int lar_ld, lar_col0, A;
 };
 
+// APG actors per workgroup: 8 when the batch fills the chip (the wall image is built once per workgroup: ~2.5 us of VALU),
+// 2 for small batches (grouped updates: 512 / 64 actors per launch), where 8 actors in a row per workgroup were 20 of the
+// launch's 23 us and most CUs had no workgroup at all
+template <int APG>
 __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   __shared__ uint4 wall_img[FRAME_BYTES / 16];
   // the workgroup's actors' scalar state, fetched by one thread per actor while the wall image is built: read inside the
   // per-actor loop, each actor would start with two dependent global round trips (state, then the previous slot's terminal
   // flag) that nothing overlaps -- 8 actors x ~2 us of a 38 us launch
-  __shared__ int s_flag[kActorsPerGroup], s_x[kActorsPerGroup], s_y[kActorsPerGroup], s_a[kActorsPerGroup],
-      s_cnt[kActorsPerGroup], s_la[kActorsPerGroup], s_prev[kActorsPerGroup], s_ns[kActorsPerGroup];
-  __shared__ float s_lr[kActorsPerGroup], s_ep[kActorsPerGroup];
-  if (threadIdx.x < kActorsPerGroup) {
-    const int k = threadIdx.x, b = blockIdx.x * kActorsPerGroup + k;
+  __shared__ int s_flag[APG], s_x[APG], s_y[APG], s_a[APG],
+      s_cnt[APG], s_la[APG], s_prev[APG], s_ns[APG];
+  __shared__ float s_lr[APG], s_ep[APG];
+  if (threadIdx.x < APG) {
+    const int k = threadIdx.x, b = blockIdx.x * APG + k;
     if (b < p.B) {
       const int cnt = p.count[b];
       s_flag[k] = p.active_rw ? p.active_rw[b] : (p.active ? p.active[b] : 1);
@@ -157,8 +161,8 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   build_wall_image(wall_img);
   __syncthreads();
   const int H1 = p.H1;
-  for (int k = 0; k < kActorsPerGroup; ++k) {
-    const int b = blockIdx.x * kActorsPerGroup + k;
+  for (int k = 0; k < APG; ++k) {
+    const int b = blockIdx.x * APG + k;
     if (b >= p.B) break;
     const int act_flag = s_flag[k];
     if (p.active_rw && threadIdx.x == 0) p.active_log_t[b] = act_flag;
@@ -479,7 +483,8 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
              nullptr, 0, 0, 0};
-  hipLaunchKernelGGL(maze_step_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
@@ -497,7 +502,8 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
              lar_col0, A};
-  hipLaunchKernelGGL(maze_step_kernel, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 

@@ -1030,8 +1030,14 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
         hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, false, 1, 1, true>), dim3(grid128), dim3(256), 0, (hipStream_t)stream, a);
       else
         hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, false, 1, 2, true>), dim3(grid128), dim3(512), 0, (hipStream_t)stream, a);
-    } else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (a.vecA) {
+      // small steps (grouped updates: 512 / 64 rows per launch): 16 x rows/64 tiles of 64 x 64 leave most CUs without a
+      // workgroup and one wave per SIMD on the others -- wave groups share a tile's 17 K tiles (as in the plain products)
+      const long tiles = (long)a.nbx * a.nby;
+      if (tiles <= 256) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 4, true>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, a);
+      else if (tiles <= 512) hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 2, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, true, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    } else hipLaunchKernelGGL((gemm_split_nt_kernel<64, 64, false, true, 1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   }
   return unreal_launch_status();
 }
