@@ -33,7 +33,7 @@ static inline int unreal_launch_status() {
 
 // ---- fp16 hi + lo operands (gemm_split.hip): per-tensor power-of-two scales -------------------------------------
 // An "absmax slot" is one float in device memory holding max |x| over a tensor.  Producers commit their outputs' maximum
-// with ONE atomic per wave (non-negative floats order like unsigned integers); consumers turn it into the power of two
+// with ONE atomic per workgroup (its waves' maxima meet in LDS first; non-negative floats order like unsigned integers); consumers turn it into the power of two
 // that puts the largest element into [2^14, 2^15) -- inside fp16's range with a factor two to spare, and deep enough that
 // hi + lo carry 22 significant bits for every element down to 2^-17 of the maximum.
 __device__ __forceinline__ float wave_max(float v) {

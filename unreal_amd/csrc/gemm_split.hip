@@ -25,7 +25,7 @@
 // fp16x2 (NT kernels).  x * s = hi + lo, both fp16 (round to nearest; hi + lo carries 22 significant bits), s the power of
 // two that puts the tensor's largest |x| into [2^14, 2^15).  The tensor maxima travel in "absmax slots" (common.h): the
 // weight's is reduced when its shadow is made, an activation's is committed by the kernel that PRODUCES it (encoder,
-// GEMM / LSTM / deconv epilogues: one atomic per wave) -- unreal_absmax_f32 is the stand-alone reduction for callers that
+// GEMM / LSTM / deconv epilogues: one atomic per workgroup) -- unreal_absmax_f32 is the stand-alone reduction for callers that
 // have none.  A product tile accumulates hh + hl + lh on v_mfma_f32_32x32x16_f16 (the dropped ll pair is < 2^-22 |ab|) and
 // is un-scaled exactly in the epilogue.  Gate (tools/exp/f16x2_gate.py, profiles/r03_f16x2_gate.log):
 // on the trainer's live operands at production shape the error against fp64 is BELOW the plain-fp32-MFMA kernel's
