@@ -146,7 +146,8 @@ int unreal_absmax_f32(int rows, int cols, const float* x, int ld, float* slot, v
  * accumulated in fp32 on v_mfma_f32_32x32x16_f16 and un-scaled exactly.  A is fp32; W2 is the weight matrix as a
  * pre-split shadow made by unreal_split_f16x2 with the SAME w_absmax slot: plane t (0 = hi, 1 = lo) at
  * W2 + t*plane_stride, row n at + n*ldw (ldw a multiple of 8 and >= K rounded up to 32, padding zero).  c_absmax
- * (nullable): receives max |C| of what this call stores.  Same epilogue flags as unreal_gemm_f32 except ATOMIC.  Used
+ * (nullable): receives max |C| of what this call stores; refused (-22) together with UNREAL_GEMM_ATOMIC / splitk > 1,
+ * whose epilogue adds partial tiles and never sees a finished element.  Same epilogue flags as unreal_gemm_f32.  Used
  * for the forward and dgrad GEMMs of the dense layers (tf.matmul call sites model/model.py:314,334,423). */
 int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W2,
                              int ldw, long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax,

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+import margins
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 B, H, T = 4096, 2000, 20
@@ -169,6 +171,7 @@ def _close(got, ref, atol, rtol, what):
     ref = ref.detach().cpu().double().numpy()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     err = np.abs(got - ref) - (atol + rtol * np.abs(ref))
+    margins.record_close(what.split(" actor ")[0].split(" of actor ")[0], got, ref, atol, rtol)
     assert err.max() <= 0, "%s: max |d| = %g (ref %g) over %s" % (what, np.abs(got - ref).max(),
                                                                   ref.flat[np.argmax(err)], (got.shape,))
 
@@ -178,6 +181,7 @@ def _close_grad(got, ref, what, rel=2e-4):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = float(ref.abs().max())
     assert scale > 0, what
+    margins.record(what.split(" actor ")[0], float((got - ref).abs().max()) / (rel * scale), "%g of max |ref|" % rel)
     assert float((got - ref).abs().max()) <= rel * scale, "%s: max |d| = %g, max |ref| = %g" % (
         what, float((got - ref).abs().max()), scale)
 
@@ -276,6 +280,7 @@ def test_fullshape_backward_kernels_match_fp64(branches):
         want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
         worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
         scale = max(scale, float(want.abs().max()))
+    margins.record("fc1 dgrad at %d rows" % rows, worst / (2e-4 * scale), "2e-4 of max |ref|")
     assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad", worst, scale)
     # conv encoder backward
     dW1, db1, dW2, db2 = z(3072), z(16), z(8192), z(32)
@@ -307,6 +312,129 @@ def test_fullshape_backward_kernels_match_fp64(branches):
     # and the trainer's own accumulation of the base branch is the same numbers
     _close_grad(net.g["W_base_conv2"].view(256, 32), r_dW2, "g[W_base_conv2] (base branch)")
     _close_grad(net.g["W_base_fc1"].view(2592, 256), ref, "g[W_base_fc1] (base branch)")
+
+
+def _check_lstm_backward(net, ws, gws, T_, Bt, d_feat, h0_nonzero, seqs, what):
+    """Backward of the recurrent chain at production shape, from the LIVE operands the pass left on the device:
+      * g[lstm_kernel] = [x | h_prev]^T . d_gates and g[lstm_bias] = column sums of d_gates over all T_*Bt rows, in fp64
+        on the device (model/model.py:339-353: one kernel for the concatenated [input, h]);
+      * d_gates of the sequences `seqs` (column b of every time block) by an fp64 BPTT through BasicLSTMCell from the
+        saved gate activations / cell states and the same d_feat (the fused unreal_lstm_bptt_step at Bt rows per step)."""
+    K_x, xld = net.K_x, ws.xld
+    rows = T_ * Bt
+    dg = gws.d_gates[:rows * 1024].view(rows, 1024)
+    x = ws.xcat[:rows * xld].view(rows, xld)[:, :K_x]
+    h_prev = torch.cat([ws.h0[:Bt * 256].view(Bt, 256) if h0_nonzero else torch.zeros(Bt, 256, device=DEV),
+                        ws.h[:(T_ - 1) * Bt * 256].view(-1, 256)])
+    ref = torch.zeros(K_x + 256, 1024, dtype=torch.float64, device=DEV)
+    for r0 in range(0, rows, 8192):
+        d64 = dg[r0:r0 + 8192].double()
+        ref[:K_x] += x[r0:r0 + 8192].double().t() @ d64
+        ref[K_x:] += h_prev[r0:r0 + 8192].double().t() @ d64
+    g = net.g["lstm_kernel"].view(K_x + 256, 1024)
+    _close_grad(g[:256], ref[:256], what + " g[lstm_kernel] fc rows (K = %d)" % rows)
+    _close_grad(g[256:K_x], ref[256:K_x], what + " g[lstm_kernel] last-action-reward rows")
+    _close_grad(g[K_x:], ref[K_x:], what + " g[lstm_kernel] recurrent rows")
+    _close_grad(net.g["lstm_bias"], dg.double().sum(0), what + " g[lstm_bias]")
+    # fp64 BPTT of the chosen sequences
+    cols = torch.as_tensor(np.asarray(seqs, dtype=np.int64), device=DEV)
+    n = len(seqs)
+    Wh = net.params.shaped("lstm_kernel")[K_x:].double()                     # [256, 1024]
+    sel = lambda buf, t, w: buf[t * Bt * w:(t + 1) * Bt * w].view(Bt, w)[cols].double()
+    dc = torch.zeros(n, 256, dtype=torch.float64, device=DEV)
+    dh_rec = torch.zeros(n, 256, dtype=torch.float64, device=DEV)
+    worst = scale = 0.0
+    for t in reversed(range(T_)):
+        ga = sel(ws.gates, t, 1024)
+        i, j, f, o = ga[:, :256], ga[:, 256:512], ga[:, 512:768], ga[:, 768:]
+        c_new = sel(ws.c, t, 256)
+        c_prev = sel(ws.c, t - 1, 256) if t > 0 else ws.c0[:Bt * 256].view(Bt, 256)[cols].double()
+        dh = sel(d_feat, t, 256) + dh_rec
+        tc = torch.tanh(c_new)
+        dc = dc + dh * o * (1 - tc * tc)
+        want = torch.cat([dc * j * i * (1 - i), dc * i * (1 - j * j), dc * c_prev * f * (1 - f), dh * tc * o * (1 - o)], 1)
+        got = sel(gws.d_gates, t, 1024)
+        worst = max(worst, float((got - want).abs().max()))
+        scale = max(scale, float(want.abs().max()))
+        dc = dc * f
+        dh_rec = want @ Wh.t()
+    margins.record(what + " d_gates of %d sequences (fp64 BPTT)" % n, worst / (2e-4 * scale), "2e-4 of max |d_gates|")
+    assert scale > 0 and worst <= 2e-4 * scale, (what, "d_gates", worst, scale)
+
+
+def test_fullshape_lstm_backward_matches_fp64(branches):
+    """g[lstm_kernel], g[lstm_bias] and d_gates of the BASE branch (81,920 rows, 4096 rows per BPTT
+    step, h0 = the carried state) -- runs while net.g holds the base branch's contribution only."""
+    flags, net, tr, actors, p64 = branches
+    if not tr.use_lstm:
+        pytest.skip("FF trunk")
+    _check_lstm_backward(net, tr.base_ws, tr.gws, T, B, tr.gws.d_feat, True, [int(b) for b in actors], "base branch")
+
+
+def _err_stats(C, R):
+    """rms error and the 99.99th-percentile |error| (both absolute; the two kernels are compared on the same R)."""
+    e = (C.double() - R).abs().flatten()
+    k = max(1, int(1e-4 * e.numel()))
+    return float(e.pow(2).mean().sqrt()), float(torch.topk(e, k).values[-1])
+
+
+def test_fullshape_split_gemms_not_worse_than_fp32_mfma_on_live_operands(branches):
+    """The fp16 hi + lo gate as a test (was tools/exp/f16x2_gate.py): the five big products of the base
+    branch re-launched on the trainer's LIVE 81,920-row operands through both kernels -- rms error and 99.99th-percentile
+    error of unreal_gemm_f32_split_nt / _tn against fp64 must not exceed the plain fp32-MFMA kernel's (unreal_gemm_f32)."""
+    from unreal_amd import ops
+    from unreal_amd.model.model import _splitk
+    flags, net, tr, actors, p64 = branches
+    if not tr.use_lstm:
+        pytest.skip("FF trunk")
+    ws, gws = tr.base_ws, tr.gws
+    rows = T * B
+    f2 = ws.f2[:rows * 2592].view(rows, 2592)
+    d_fc = gws.d_fc[:rows * 256].view(rows, 256)
+    d_gates = gws.d_gates[:rows * 1024].view(rows, 1024)
+    xc = ws.xcat[:rows * ws.xld].view(rows, ws.xld)[:, :256].contiguous()
+    W_fc1 = net.params.shaped("W_base_fc1")                     # [2592, 256]
+    W_l = net.params.shaped("lstm_kernel")[:256]                # [256, 1024]
+
+    def ref_nt(A, Wkn):                                         # A [rows,K] @ Wkn [K,N]
+        return torch.cat([A[r0:r0 + 8192].double() @ Wkn.double() for r0 in range(0, rows, 8192)])
+
+    def ref_tn(A, Bm):
+        out = torch.zeros(A.shape[1], Bm.shape[1], dtype=torch.float64, device=DEV)
+        for r0 in range(0, rows, 8192):
+            out += A[r0:r0 + 8192].double().t() @ Bm[r0:r0 + 8192].double()
+        return out
+
+    nt_cases = [("fc forward f2 x W_fc1 [K 2592]", f2, W_fc1, True),               # weights given as [K, N]: transpose
+                ("fc dgrad d_fc x W_fc1^T [K 256]", d_fc, W_fc1, False),           # weights given as [N, K]
+                ("lstm dgrad d_gates x Wl^T [K 1024]", d_gates, W_l, False)]
+    for name, A, W, transpose in nt_cases:
+        K = A.shape[1]
+        N = W.shape[1] if transpose else W.shape[0]
+        R = ref_nt(A, W if transpose else W.t())
+        sh = ops.SplitWeights(W.contiguous().view(-1), W.shape[0], W.shape[1], W.shape[1], transpose)
+        C = torch.empty(rows, N, device=DEV)
+        ops.gemm_split_nt(rows, N, K, A, A.stride(0), sh, C, N)
+        Wnk = (W.t() if transpose else W).contiguous()
+        C32 = torch.empty(rows, N, device=DEV)
+        ops.gemm(False, True, rows, N, K, A, A.stride(0), Wnk, K, C32, N)
+        (r16, p16), (r32, p32) = _err_stats(C, R), _err_stats(C32, R)
+        margins.record("live gate: " + name + " rms", r16 / r32, "1 x unreal_gemm_f32")
+        margins.record("live gate: " + name + " p99.99", p16 / p32, "1 x unreal_gemm_f32")
+        assert r16 <= r32 and p16 <= p32, (name, r16, r32, p16, p32)
+        del R, C, C32
+    for name, A, Bm in [("fc wgrad f2^T x d_fc [K %d]" % rows, f2, d_fc), ("lstm wgrad fc^T x d_gates [K %d]" % rows, xc, d_gates)]:
+        M_, N_ = A.shape[1], Bm.shape[1]
+        R = ref_tn(A, Bm)
+        sk = _splitk(M_, N_, rows)
+        C = torch.zeros(M_, N_, device=DEV)
+        ops.gemm_split_tn(M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C, N_, splitk=sk)
+        C32 = torch.zeros(M_, N_, device=DEV)
+        ops.gemm(True, False, M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C32, N_, flags=ops.GEMM_ATOMIC, splitk=sk)
+        (r16, p16), (r32, p32) = _err_stats(C, R), _err_stats(C32, R)
+        margins.record("live gate: " + name + " rms", r16 / r32, "1 x unreal_gemm_f32")
+        margins.record("live gate: " + name + " p99.99", p16 / p32, "1 x unreal_gemm_f32")
+        assert r16 <= r32 and p16 <= p32, (name, r16, r32, p16, p32)
 
 
 def test_fullshape_pixel_control_rows_match_oracle(branches):
@@ -448,6 +576,7 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
         scale = max(scale, float(want.abs().max()))
         r_dW += torch.einsum("nkp,ncp->kc", F.unfold(dd, 4, stride=2), h.reshape(n, 32, 81))
         r_db += dd.sum((0, 2, 3))
+    margins.record("pc deconv dgrad on every other row", worst / (2e-4 * scale), "2e-4 of max |ref|")
     assert scale > 0 and worst <= 2e-4 * scale, ("pc deconv dgrad on every other row", worst, scale)
     r_dW = r_dW.view(1 + A, 4, 4, 32).permute(1, 2, 0, 3)                          # [ky,kx,o,c]
     _close_grad(g["W_pc_deconv_v"].view(4, 4, 1, 32), r_dW[:, :, :1], "g[W_pc_deconv_v]")
@@ -475,6 +604,7 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
         want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
         worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
         scale = max(scale, float(want.abs().max()))
+    margins.record("fc1 dgrad at %d rows" % rows2, worst / (2e-4 * scale), "2e-4 of max |ref|")
     assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad at %d rows" % rows2, worst, scale)
     # ---- conv encoder backward at 163,840 frames -----------------------------------------------------------------------
     W2 = net.params.shaped("W_base_conv2").double()
@@ -501,3 +631,57 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
     _close_grad(g["b_base_conv2"], r_db2, "g[b_base_conv2] increment")
     _close_grad(g["W_base_conv1"].view(192, 16), r_dW1, "g[W_base_conv1] increment")
     _close_grad(g["b_base_conv1"], r_db1, "g[b_base_conv1] increment")
+    # ---- recurrent chain at 8192 rows per step ----------------------------------------------------
+    if tr.use_lstm:
+        seqs = [2 * int(b) + s_ for b in actors[:32] for s_ in (0, 1)]
+        _check_lstm_backward(net, ws, gws, Ta, 2 * B, gws.d_feat, False, seqs, "batched replay pass")
+
+
+def test_fullshape_reward_prediction_backward_matches_fp64(branches):
+    """the reward-prediction branch's backward at production shape (4096 samples = 12,288 frames):
+    g[W_rp_fc1] / g[b_rp_fc1] (unreal_linear_small_bwd<3> at K = 7776), its d_f2 with the conv2 ReLU mask, and the conv
+    gradients of the 12,288-frame encoder_bwd -- against fp64 on the device from the live operands
+    (model/model.py:473-488, 569-576)."""
+    import torch.nn.functional as F
+    flags, net, tr, actors, p64 = branches
+    if not tr.use_reward_prediction:
+        pytest.skip("reward prediction off")
+    net.begin_pass()
+    net.grads.flat.zero_()
+    tr.losses.zero_()
+    tr._train_rp()
+    torch.cuda.synchronize()
+    ws, gws, ring, g = tr.rp_ws, tr.gws, tr.ring, net.g
+    f2 = ws.f2[:3 * B * 2592].view(B, 7776)
+    dl = tr.rp_dlogits.view(B, 3)
+    W = net.params.shaped("W_rp_fc1").double()                                     # [7776, 3]
+    _close_grad(g["W_rp_fc1"].view(7776, 3), f2.double().t() @ dl.double(), "g[W_rp_fc1] at %d samples" % B)
+    _close_grad(g["b_rp_fc1"], dl.double().sum(0), "g[b_rp_fc1]")
+    d_f2 = gws.d_f2[:3 * B * 2592].view(3 * B, 2592)
+    want = ((dl.double() @ W.t()) * (f2 > 0)).view(3 * B, 2592)
+    _close_grad(d_f2, want, "reward-prediction d_f2 (masked)")
+    rows = 3 * B
+    W2 = net.params.shaped("W_base_conv2").double()
+    w2_oihw = W2.permute(3, 2, 0, 1).contiguous()
+    r_dW2 = torch.zeros(256, 32, dtype=torch.float64, device=DEV)
+    r_dW1 = torch.zeros(192, 16, dtype=torch.float64, device=DEV)
+    r_db1 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    r_db2 = torch.zeros(32, dtype=torch.float64, device=DEV)
+    frames4 = ring.frames.view(-1, 84, 84, 3)
+    CH = 1024
+    for r0 in range(0, rows, CH):
+        n = min(CH, rows - r0)
+        c1 = ws.c1[r0 * 6400:(r0 + n) * 6400].view(n, 20, 20, 16).double().permute(0, 3, 1, 2)
+        d2 = d_f2[r0:r0 + n].double().view(n, 9, 9, 32).permute(0, 3, 1, 2).contiguous()
+        r_db2 += d2.sum((0, 2, 3))
+        r_dW2 += torch.einsum("nkp,nop->ko", F.unfold(c1, 4, stride=2), d2.reshape(n, 32, 81))
+        d1 = F.conv_transpose2d(d2, w2_oihw, stride=2) * (c1 > 0)
+        r_db1 += d1.sum((0, 2, 3))
+        x = frames4[ws.frame_idx[r0:r0 + n].long()].double().permute(0, 3, 1, 2) * net.frame_scale
+        r_dW1 += torch.einsum("nkp,nop->ko", F.unfold(x, 8, stride=4), d1.reshape(n, 16, 400))
+    r_dW2 = r_dW2.view(16, 4, 4, 32).permute(1, 2, 0, 3).reshape(256, 32)
+    r_dW1 = r_dW1.view(3, 8, 8, 16).permute(1, 2, 0, 3).reshape(192, 16)
+    _close_grad(g["W_base_conv2"].view(256, 32), r_dW2, "g[W_base_conv2] of the reward-prediction branch (%d frames)" % rows)
+    _close_grad(g["b_base_conv2"], r_db2, "g[b_base_conv2] (rp)")
+    _close_grad(g["W_base_conv1"].view(192, 16), r_dW1, "g[W_base_conv1] (rp)")
+    _close_grad(g["b_base_conv1"], r_db1, "g[b_base_conv1] (rp)")

@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import margins
+
 pytestmark = pytest.mark.gpu
 
 from oracle import maze as OM
@@ -40,6 +42,7 @@ def close(got, ref, atol=2e-5, rtol=2e-5, what=""):
     ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
     err = np.abs(got - ref) - (atol + rtol * np.abs(ref))
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    margins.record_close(what, got, ref, atol, rtol)
     assert err.max() <= 0, "%s: max |d|=%g at %s (ref %g)" % (
         what, np.abs(got - ref).max(), np.unravel_index(np.argmax(err), err.shape), ref.flat[np.argmax(err)])
 

@@ -1,0 +1,379 @@
+"""Dynamic-range stress of the fp16 hi + lo ("fp16x2") kernels -- VERDICT r3 item 1a.
+
+Every GEMM-shaped product of the path splits its fp32 operands into fp16 hi + lo planes under ONE power-of-two scale per
+tensor (csrc/common.h: the tensor's largest element lands in [2^14, 2^15)).  hi + lo carries 22 significant bits for an
+element down to 2^-17 of the tensor maximum; below that lo goes fp16-subnormal (absolute spacing 2^-24 in scaled units =
+2^-39 .. 2^-38 of the maximum), and below 2^-28 hi does too.  These tests put operand rows -- and, separately, reduction
+columns and weight rows -- at 2^0 ... 2^-30 of the tensor maximum IN ONE LAUNCH, so that lo is normal, subnormal and
+flushed side by side, and assert
+
+  (1) per OUTPUT:  |err| <= C_REL * 2^-22 * sum_k |a_k| |b_k|  +  2^-38 * max|a| * max|b| * K
+      (fp64 arbiter; the absolute term is the scheme's own floor and nothing above it: no other absolute slack);
+  (2) per output ROW inside the 22-bit range (exponent >= -16): max |err| of the row <= 2 x the plain fp32 kernel's
+      (unreal_gemm_f32) on the same data.  Rows below the range are held to (1) only -- a per-tensor scale gives them
+      ABSOLUTE accuracy (2^-38 of the tensor maximum), not relative; their ratio to the fp32 kernel is recorded in
+      profiles/r04_parity_margins.md, not asserted.  This is the documented contract of the format.
+
+The conv / deconv kernels have no fp32 twin in the library: they are held to (1) against the fp64 restatement
+(torch conv in float64, the arithmetic of oracle/model.py:encoder / pc_head)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import margins
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+C_REL = 1.5          # (1): multiples of 2^-22 sum |a||b| (fp32-grade accumulation + two 22-bit operands)
+U22, U38 = 2.0 ** -22, 2.0 ** -38
+NORMAL_E = 16        # rows at 2^-e, e <= NORMAL_E: inside the 22-bit range of hi + lo
+
+
+def dev32(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(DEV).contiguous()
+
+
+def _exps(n):
+    """Exponent 0..30 for each of n rows (row r sits at 2^-(r % 31) of the maximum)."""
+    return np.arange(n) % 31
+
+
+def _check_bound(what, err, S, floor, c=C_REL):
+    """(1): err, S tensors (float64, device); floor a Python float or a broadcastable tensor."""
+    bound = c * U22 * S + floor
+    ratio = float((err / bound).max())
+    # how much of the worst element's bar is the relative part (1 = pure 2^-22 sum|a||b|; ~0 = on the absolute floor)
+    k = int(torch.argmax(err / bound))
+    rel_share = float((c * U22 * S).flatten()[k] / bound.flatten()[k])
+    margins.record(what, ratio, "%.1f*2^-22*sum|a||b| + 2^-38*max|a|*max|b|*K" % c,
+                   note="relative share of the bar at the worst output %.2g" % rel_share)
+    assert ratio <= 1.0, "%s: worst |err| / bound = %.3f" % (what, ratio)
+
+
+def _check_rows_vs_fp32(what, err, err32, e, axis):
+    """(2): per output row (axis = 1: reduce over columns) or output column (axis = 0), grouped by exponent e."""
+    r16 = err.amax(dim=axis).cpu().numpy()
+    r32 = err32.amax(dim=axis).cpu().numpy()
+    ratio = r16 / np.maximum(r32, 1e-300)
+    inside = e <= NORMAL_E
+    worst_in = float(ratio[inside].max())
+    margins.record(what + " rows with exponent >= -%d: row max |err| vs unreal_gemm_f32" % NORMAL_E, worst_in / 2.0,
+                   "2 x the fp32 kernel's")
+    if (~inside).any():
+        by_e = {int(k): float(ratio[e == k].max()) for k in np.unique(e[~inside])}
+        margins.record(what + " rows below 2^-%d (recorded, not asserted)" % NORMAL_E, float(ratio[~inside].max()),
+                       "x the fp32 kernel's row error", note="by exponent: " + ", ".join("-%d: %.3g" % kv for kv in sorted(by_e.items())))
+    assert worst_in <= 2.0, "%s: a row inside the 22-bit range has %.2f x the fp32 kernel's error" % (what, worst_in)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(992, 256, 2592), (992, 2592, 256), (4096, 256, 1024), (62, 1024, 261)])
+@pytest.mark.parametrize("which", ["rows", "kcols", "wrows", "rows+kcols"])
+def test_split_nt_dynamic_range(M, N, K, which):
+    """unreal_gemm_f32_split_nt (fc forward / fc dgrad / LSTM dgrad shapes + a ragged one)."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(M + N + K + len(which))
+    A = rs.standard_normal((M, K))
+    W = rs.standard_normal((N, K)) * 0.05
+    e_row, e_col = np.zeros(M, dtype=int), np.zeros(N, dtype=int)
+    if "rows" in which.split("+"):
+        e_row = _exps(M)
+        A *= 2.0 ** -e_row[:, None]
+    if "kcols" in which.split("+"):
+        A *= 2.0 ** -_exps(K)[None, :]
+    if which == "wrows":
+        e_col = _exps(N)
+        W *= 2.0 ** -e_col[:, None]
+    Ad, Wd = dev32(A), dev32(W)
+    ref = Ad.double() @ Wd.double().t()
+    S = Ad.double().abs() @ Wd.double().abs().t()
+    sh = ops.SplitWeights(Wd, N, K, K, transpose=False)
+    C = torch.zeros(M, N, device=DEV)
+    ops.gemm_split_nt(M, N, K, Ad, K, sh, C, N)
+    C32 = torch.zeros(M, N, device=DEV)
+    ops.gemm(0, 1, M, N, K, Ad, K, Wd, K, C32, N)
+    err, err32 = (C.double() - ref).abs(), (C32.double() - ref).abs()
+    floor = U38 * float(Ad.abs().max()) * float(Wd.abs().max()) * K
+    tag = "split_nt %dx%dx%d %s" % (M, N, K, which)
+    _check_bound(tag, err, S, floor)
+    if which == "wrows":
+        _check_rows_vs_fp32(tag, err, err32, e_col, axis=0)
+    else:
+        _check_rows_vs_fp32(tag, err, err32, e_row, axis=1)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 8192), (2592, 256, 4096), (261, 130, 1000)])
+@pytest.mark.parametrize("which", ["krows", "mcols", "krows_both"])
+def test_split_tn_dynamic_range(M, N, K, which):
+    """unreal_gemm_f32_split_tn (wgrad): C[M,N] += A[K,M]^T B[K,N].  krows: the reduction rows of A at 2^0..2^-30
+    (krows_both: of A and B, products down to 2^-60); mcols: A's columns, i.e. the output rows."""
+    from unreal_amd import ops
+    from unreal_amd.model.model import _splitk
+    rs = np.random.RandomState(M + N + K + len(which))
+    lda, ldb = (M + 3) // 4 * 4, (N + 3) // 4 * 4
+    A = np.zeros((K, lda)); B = np.zeros((K, ldb))
+    A[:, :M] = rs.standard_normal((K, M)); B[:, :N] = rs.standard_normal((K, N)) * 0.1
+    e_row = np.zeros(M, dtype=int)
+    if which.startswith("krows"):
+        A *= 2.0 ** -_exps(K)[:, None]
+        if which == "krows_both":
+            B *= 2.0 ** -_exps(K)[:, None]
+    else:
+        e_row = _exps(M)
+        A[:, :M] *= 2.0 ** -e_row[None, :]
+    Ad, Bd = dev32(A), dev32(B)
+    A64, B64 = Ad[:, :M].double(), Bd[:, :N].double()
+    ref = A64.t() @ B64
+    S = A64.abs().t() @ B64.abs()
+    sk = _splitk(M, N, K)
+    C = torch.zeros(M, N, device=DEV)
+    ops.gemm_split_tn(M, N, K, Ad, lda, Bd, ldb, C, N, splitk=sk)
+    C32 = torch.zeros(M, N, device=DEV)
+    ops.gemm(1, 0, M, N, K, Ad, lda, Bd, ldb, C32, N, flags=ops.GEMM_ATOMIC, splitk=sk)
+    err, err32 = (C.double() - ref).abs(), (C32.double() - ref).abs()
+    floor = U38 * float(Ad.abs().max()) * float(Bd.abs().max()) * K
+    tag = "split_tn %dx%dx%d %s" % (M, N, K, which)
+    _check_bound(tag, err, S, floor)
+    _check_rows_vs_fp32(tag, err, err32, e_row, axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _enc_inputs(rs, N, which):
+    """fp32-representable encoder weights (float64 tensors) with output channels at 2^0 .. 2^-30."""
+    from oracle import model as OMod
+    p = OMod.init_params(4, seed=5, dtype=torch.float64)
+    p["b_base_conv1"] = torch.tensor(rs.uniform(-.05, .05, 16))
+    e1 = np.zeros(16, dtype=int); e2 = np.zeros(32, dtype=int)
+    if which == "w1ch":                       # conv1 output channels: c1 channels AND conv2's reduction columns
+        e1 = 2 * np.arange(16)
+    elif which == "w2ch":                     # conv2 output channels
+        e2 = np.minimum(np.arange(32), 30)
+    elif which == "w2k":                      # conv2's input-channel rows (reduction columns of conv2 only)
+        p["W_base_conv2"] = p["W_base_conv2"] * torch.tensor(2.0 ** -(2.0 * np.arange(16))).reshape(1, 1, 16, 1)
+    p["W_base_conv1"] = p["W_base_conv1"] * torch.tensor(2.0 ** -e1.astype(np.float64))
+    p["b_base_conv1"] = p["b_base_conv1"] * torch.tensor(2.0 ** -e1.astype(np.float64))
+    p["W_base_conv2"] = p["W_base_conv2"] * torch.tensor(2.0 ** -e2.astype(np.float64))
+    p["b_base_conv2"] = p["b_base_conv2"] * torch.tensor(2.0 ** -e2.astype(np.float64))
+    for k in ("W_base_conv1", "b_base_conv1", "W_base_conv2", "b_base_conv2"):
+        p[k] = p[k].float().double()
+    return p, e1, e2
+
+
+@pytest.mark.parametrize("which", ["plain", "w1ch", "w2ch", "w2k"])
+@pytest.mark.parametrize("mode", ["u8", "maze"])
+def test_encoder_fwd_dynamic_range(which, mode):
+    """unreal_encoder_fwd: conv1 (c1) and conv2 (f2) against float64 with the per-output bound (1).  The c1 planes' scale is
+    the kernel's a-priori bound B1 = max_c(pixel_max * ||W1[:, c]||_1 + |b1_c|), so B1 takes max |a|'s place in conv2's floor."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(len(which) * 7 + len(mode))
+    N = 48
+    p, e1, e2 = _enc_inputs(rs, N, which)
+    if mode == "maze":
+        pool = rs.randint(0, 2, size=(N, 84, 84, 3)).astype(np.uint8); scale = 1.0
+    else:
+        pool = rs.randint(0, 256, size=(N, 84, 84, 3)).astype(np.uint8); scale = 1.0 / 255.0
+    idx = np.arange(N, dtype=np.int32)
+    x = (torch.tensor(pool.astype(np.float64)) * scale).to(DEV).permute(0, 3, 1, 2)
+    P = {k: v.to(DEV) for k, v in p.items()}
+    w1 = P["W_base_conv1"].permute(3, 2, 0, 1); w2 = P["W_base_conv2"].permute(3, 2, 0, 1)
+    pre1 = F.conv2d(x, w1, P["b_base_conv1"], stride=4)
+    h1 = F.relu(pre1)
+    h2 = F.relu(F.conv2d(h1, w2, P["b_base_conv2"], stride=2))
+    S1 = F.conv2d(x.abs(), w1.abs(), P["b_base_conv1"].abs(), stride=4)
+    S2 = F.conv2d(S1, w2.abs(), P["b_base_conv2"].abs(), stride=2)
+    xmax = 255.0 * scale if mode == "u8" else 1.0
+    B1 = float((xmax * w1.abs().sum((1, 2, 3)) + P["b_base_conv1"].abs()).max())
+    floor1 = U38 * xmax * float(w1.abs().max()) * 192
+    floor2 = U38 * B1 * float(w2.abs().max()) * 256 + float(w2.abs().sum((1, 2, 3)).max()) * floor1
+    f2 = torch.zeros(N * 2592, device=DEV); c1 = torch.zeros(N * 6400, device=DEV)
+    f = lambda k: P[k].float().contiguous().view(-1)
+    ops.encoder_fwd(torch.as_tensor(pool.reshape(-1)).to(DEV), torch.as_tensor(idx).to(DEV), scale, f("W_base_conv1"),
+                    f("b_base_conv1"), f("W_base_conv2"), f("b_base_conv2"), f2, c1)
+    got1 = c1.view(N, 20, 20, 16).permute(0, 3, 1, 2).double()
+    got2 = f2.view(N, 9, 9, 32).permute(0, 3, 1, 2).double()
+    tag = "encoder_fwd %s %s" % (mode, which)
+    _check_bound(tag + " conv1", (got1 - h1).abs(), S1, floor1)
+    _check_bound(tag + " conv2", (got2 - h2).abs(), S2, floor2, c=2 * C_REL)     # its own rounding + conv1's, propagated
+    # against SURVEY 8d's forward bar as well (1e-5 abs + 1e-5 rel)
+    margins.record_close(tag + " conv2 vs 1e-5 + 1e-5", got2.cpu().numpy(), h2.cpu().numpy(), 1e-5, 1e-5)
+    assert float(((got2 - h2).abs() - (1e-5 + 1e-5 * h2.abs())).max()) <= 0
+
+
+@pytest.mark.parametrize("which", ["plain", "d2rows", "d2ch", "c1ch"])
+def test_encoder_bwd_dynamic_range(which):
+    """unreal_encoder_bwd: dW2, db2, dW1, db1 (sums over the frames) against float64 with bound (1); d2rows puts the FRAMES'
+    gradients at 2^0..2^-30, d2ch conv2's output channels, c1ch the saved conv1 activation's channels."""
+    from unreal_amd import ops
+    from oracle import model as OMod
+    rs = np.random.RandomState(11 + len(which))
+    N = 93
+    scale = 1.0 / 255.0
+    pool = rs.randint(0, 256, size=(N, 84, 84, 3)).astype(np.uint8)
+    W2 = OMod.init_params(4, seed=6, dtype=torch.float64)["W_base_conv2"].float().double().to(DEV)     # [4,4,16,32]
+    c1 = np.maximum(rs.standard_normal((N, 16, 20, 20)), 0)
+    d2 = rs.standard_normal((N, 32, 9, 9)) * 1e-2
+    if which == "d2rows":
+        d2 *= 2.0 ** -_exps(N)[:, None, None, None]
+    elif which == "d2ch":
+        d2 *= 2.0 ** -np.minimum(np.arange(32), 30)[None, :, None, None]
+    elif which == "c1ch":
+        c1 *= 2.0 ** -(2.0 * np.arange(16))[None, :, None, None]
+    c1d = dev32(c1.transpose(0, 2, 3, 1)); d2d = dev32(d2.transpose(0, 2, 3, 1))                           # NHWC for the kernel
+    c1_64 = c1d.double().permute(0, 3, 1, 2); d2_64 = d2d.double().permute(0, 3, 1, 2).contiguous()
+    x = (torch.tensor(pool.astype(np.float64)) * scale).to(DEV).permute(0, 3, 1, 2)
+    w2_oihw = W2.permute(3, 2, 0, 1).contiguous()
+
+    def grads(c1_, d2_, w2_, x_, mask):
+        dW2 = torch.einsum("nkp,nop->ko", F.unfold(c1_, 4, stride=2), d2_.reshape(N, 32, 81))
+        d1 = F.conv_transpose2d(d2_, w2_, stride=2) * mask
+        dW1 = torch.einsum("nkp,nop->ko", F.unfold(x_, 8, stride=4), d1.reshape(N, 16, 400))
+        return (dW2.view(16, 4, 4, 32).permute(1, 2, 0, 3), d2_.sum((0, 2, 3)), dW1.view(3, 8, 8, 16).permute(1, 2, 0, 3),
+                d1.sum((0, 2, 3)), d1)
+
+    mask = (c1_64 > 0).double()
+    r_dW2, r_db2, r_dW1, r_db1, _ = grads(c1_64, d2_64, w2_oihw, x, mask)
+    s_dW2, s_db2, s_dW1, s_db1, s_d1 = grads(c1_64.abs(), d2_64.abs(), w2_oihw.abs(), x.abs(), mask)
+    dW1, db1, dW2, db2 = (torch.zeros(n, device=DEV) for n in (3072, 16, 8192, 32))
+    ops.encoder_bwd(torch.as_tensor(pool.reshape(-1)).to(DEV), torch.arange(N, dtype=torch.int32, device=DEV), scale,
+                    W2.float().contiguous().view(-1), c1d.view(-1), d2d.view(-1), dW1, db1, dW2, db2)
+    c1max, d2max, w2max = float(c1d.abs().max()), float(d2d.abs().max()), float(W2.abs().max())
+    D1B = d2max * float(w2_oihw.abs().sum((0, 2, 3)).max())        # the kernel's L1 bound of |d1| (scale of the d1 planes)
+    floor_d1 = U38 * d2max * w2max * 128
+    tag = "encoder_bwd %s" % which
+    _check_bound(tag + " dW2", (dW2.view(4, 4, 16, 32).double() - r_dW2).abs(), s_dW2, U38 * c1max * d2max * 81 * N)
+    _check_bound(tag + " db2", (db2.double() - r_db2).abs(), s_db2, 0.0)
+    _check_bound(tag + " dW1", (dW1.view(8, 8, 3, 16).double() - r_dW1).abs(), s_dW1,
+                 U38 * 1.0 * D1B * 400 * N + 400 * N * floor_d1, c=2 * C_REL)
+    _check_bound(tag + " db1", (db1.double() - r_db1).abs(), s_db1, 400 * N * floor_d1, c=2 * C_REL)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _pc_ref(hp, Wv, bv, Wa, ba):
+    """float64 pixel-control deconvolution (oracle/model.py:pc_head arithmetic) on NCHW hp; returns pre-activations."""
+    v_pre = F.conv_transpose2d(hp, Wv.permute(3, 2, 0, 1), bv, stride=2)
+    a_pre = F.conv_transpose2d(hp, Wa.permute(3, 2, 0, 1), ba, stride=2)
+    return v_pre, a_pre
+
+
+@pytest.mark.parametrize("which", ["plain", "rows", "ch"])
+@pytest.mark.parametrize("A", [4, 6])
+def test_pc_deconv_fwd_dynamic_range(which, A):
+    """unreal_pc_deconv_fwd: Q-max (inference) and d(loss)/d(pre-activation) + loss (training) with the FRAMES' hp rows
+    (rows) or hp's channels (ch) at 2^0..2^-30 of the tensor maximum."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(3 * A + len(which))
+    N = 62
+    lam, gs = 0.05, 0.25
+    hp = np.maximum(rs.standard_normal((N, 32, 9, 9)), 0)
+    if which == "rows":
+        hp *= 2.0 ** -_exps(N)[:, None, None, None]
+    elif which == "ch":
+        hp *= 2.0 ** -np.minimum(np.arange(32), 30)[None, :, None, None]
+    hpd = dev32(hp.transpose(0, 2, 3, 1))
+    hp64 = hpd.double().permute(0, 3, 1, 2)
+    mk = lambda *s: dev32(rs.uniform(-.1, .1, s))
+    Wv, bv, Wa, ba = mk(4, 4, 1, 32), mk(1), mk(4, 4, A, 32), mk(A)
+    v_pre, a_pre = _pc_ref(hp64, Wv.double(), bv.double(), Wa.double(), ba.double())
+    Sv, Sa = _pc_ref(hp64.abs(), Wv.double().abs(), bv.double().abs(), Wa.double().abs(), ba.double().abs())
+    v, a = F.relu(v_pre), F.relu(a_pre)
+    q = v + a - a.mean(1, keepdim=True)                                   # [N,A,20,20]
+    hpmax, wmax = float(hpd.abs().max()), float(max(Wv.abs().max(), Wa.abs().max()))
+    floor = 3 * U38 * hpmax * wmax * 128
+    Sq = Sv + 2 * Sa.amax(1, keepdim=True)                                # |v| + |a_k| + mean |a|
+    qmax = torch.zeros(N * 400, device=DEV)
+    ops.pc_deconv_fwd(N, A, hpd.view(-1), Wv.view(-1), bv, Wa.view(-1), ba, qmax=qmax)
+    tag = "pc_deconv_fwd A=%d %s" % (A, which)
+    _check_bound(tag + " qmax", (qmax.view(N, 20, 20).double() - q.amax(1)).abs(), Sq[:, 0], floor)
+    # training mode
+    act = rs.randint(0, A, N)
+    tgt = dev32(rs.uniform(0, 1, (N, 20, 20)))
+    if which == "rows":
+        tgt = tgt * torch.tensor(2.0 ** -_exps(N), dtype=torch.float32, device=DEV).view(N, 1, 1)
+    mask = (rs.rand(N) < 0.9).astype(np.int32); mask[0] = 1
+    actd = torch.as_tensor(act.astype(np.int32)).to(DEV)
+    d_dec = torch.zeros(N * 400 * (1 + A), device=DEV); ls = torch.zeros(1, device=DEV)
+    ops.pc_deconv_fwd(N, A, hpd.view(-1), Wv.view(-1), bv, Wa.view(-1), ba, action=actd, target=tgt.view(-1),
+                      mask=torch.as_tensor(mask).to(DEV), lam=lam, grad_scale=gs, d_dec=d_dec, loss=ls)
+    m = torch.as_tensor(mask.astype(np.float64)).to(DEV).view(N, 1, 1)
+    oh = F.one_hot(actd.long(), A).double()                               # [N,A]
+    qa = (q * oh.view(N, A, 1, 1)).sum(1)
+    diff = (qa - tgt.double()) * m * lam * gs                             # d(loss * gs) / d(q_a)
+    want_v = diff * (v_pre[:, 0] > 0)
+    want_a = diff.unsqueeze(1) * (oh.view(N, A, 1, 1) - 1.0 / A) * (a_pre > 0)
+    want = torch.cat([want_v.unsqueeze(1), want_a], 1).permute(0, 2, 3, 1).reshape(N, 400, 1 + A)
+    got = d_dec.view(N, 400, 1 + A).double()
+    bq = C_REL * U22 * Sq[:, 0] + floor                                   # bound of |q error|  [N,20,20]
+    bound = lam * gs * (bq + 2.0 ** -22 * (tgt.double().abs() + Sq[:, 0]))
+    pre = torch.cat([v_pre, a_pre], 1).permute(0, 2, 3, 1).reshape(N, 400, 1 + A)
+    edge = pre.abs() <= (C_REL * U22 * torch.cat([Sv, Sa], 1).permute(0, 2, 3, 1).reshape(N, 400, 1 + A) + floor)
+    errd = (got - want).abs()
+    errd[edge] = 0                                                        # ReLU'(0): either side is right
+    ratio = float((errd / bound.reshape(N, 400, 1)).max())
+    margins.record(tag + " d_dec", ratio, "lam*gs*(q bound + 2^-22 (|R| + sum|a||b|))")
+    assert ratio <= 1.0, (tag, ratio)
+    loss = 0.5 * lam * gs * (((qa - tgt.double()) ** 2) * m).sum()
+    lbound = lam * gs * float((((qa - tgt.double()).abs() * m) * bq).sum()) + 3e-7 * float(loss)
+    margins.record(tag + " loss", abs(float(ls[0]) - float(loss)) / lbound, "sum |R - q| * q bound + 3e-7 rel")
+    assert abs(float(ls[0]) - float(loss)) <= lbound, (float(ls[0]), float(loss), lbound)
+
+
+@pytest.mark.parametrize("which", ["plain", "rows", "ch", "hprows"])
+@pytest.mark.parametrize("A", [4, 3])
+def test_pc_deconv_bwd_dynamic_range(which, A):
+    """unreal_pc_deconv_bwd: d_hp (per frame) and dW / db of both deconvolutions (sums over the frames) with d_dec's frame
+    rows (rows), d_dec's channels (ch) or hp's frame rows (hprows) at 2^0..2^-30."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(5 * A + len(which))
+    N = 62
+    hp = np.maximum(rs.standard_normal((N, 32, 9, 9)), 0)
+    dd = rs.standard_normal((N, 1 + A, 20, 20)) * 1e-3
+    if which == "rows":
+        dd *= 2.0 ** -_exps(N)[:, None, None, None]
+    elif which == "ch":
+        dd *= 2.0 ** -(6.0 * np.arange(1 + A))[None, :, None, None]
+    elif which == "hprows":
+        hp *= 2.0 ** -_exps(N)[:, None, None, None]
+    hpd = dev32(hp.transpose(0, 2, 3, 1)); ddd = dev32(dd.transpose(0, 2, 3, 1).reshape(N, 400, 1 + A))
+    hp64 = hpd.double().permute(0, 3, 1, 2); dd64 = ddd.double().view(N, 20, 20, 1 + A).permute(0, 3, 1, 2).contiguous()
+    mk = lambda *s: dev32(rs.uniform(-.1, .1, s))
+    Wv, Wa = mk(4, 4, 1, 32), mk(4, 4, A, 32)
+    Wcat = torch.cat([Wv.double().permute(3, 2, 0, 1), Wa.double().permute(3, 2, 0, 1)], 1).contiguous()   # [32,1+A,4,4]
+    mask = (hp64 > 0).double()
+
+    def grads(dd_, W_, h_):
+        d_hp = F.conv2d(dd_, W_, stride=2) * mask
+        dW = torch.einsum("nkp,ncp->kc", F.unfold(dd_, 4, stride=2), h_.reshape(N, 32, 81)).view(1 + A, 4, 4, 32).permute(1, 2, 0, 3)
+        return d_hp, dW, dd_.sum((0, 2, 3))
+
+    r_dhp, r_dW, r_db = grads(dd64, Wcat, hp64)
+    s_dhp, s_dW, s_db = grads(dd64.abs(), Wcat.abs(), hp64.abs())
+    d_hp = torch.zeros(N * 2592, device=DEV)
+    dWv, dbv, dWa, dba = (torch.zeros(n, device=DEV) for n in (512, 1, 512 * A, A))
+    ops.pc_deconv_bwd(N, A, hpd.view(-1), ddd.view(-1), Wv.view(-1), Wa.view(-1), d_hp, dWv, dbv, dWa, dba)
+    ddmax, hpmax, wmax = float(ddd.abs().max()), float(hpd.abs().max()), float(Wcat.abs().max())
+    tag = "pc_deconv_bwd A=%d %s" % (A, which)
+    _check_bound(tag + " d_hp", (d_hp.view(N, 9, 9, 32).permute(0, 3, 1, 2).double() - r_dhp).abs(), s_dhp,
+                 U38 * ddmax * wmax * 16 * (1 + A))
+    got_dW = torch.cat([dWv.view(4, 4, 1, 32), dWa.view(4, 4, A, 32)], 2).double()
+    _check_bound(tag + " dW", (got_dW - r_dW).abs(), s_dW, U38 * ddmax * hpmax * 81 * N)
+    got_db = torch.cat([dbv, dba]).double()
+    _check_bound(tag + " db", (got_db - r_db).abs(), s_db, 0.0)
+
+
+def test_absmax_slot_is_committed_by_every_producer_variant():
+    """every kernel variant that accepts a c_max slot leaves max |C| in it (a slot that stayed 0 would turn the
+    consumer's scale into 1 silently); the split-K form refuses one."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(0)
+    for (M, N, K) in [(4096, 256, 512), (130, 2592, 256), (70, 256, 96), (512, 256, 2592), (1500, 1024, 200)]:   # 128^2, 64^2 KW 1/2/4
+        A = dev32(rs.standard_normal((M, K))); W = dev32(rs.standard_normal((N, K)) * 0.05)
+        sh = ops.SplitWeights(W, N, K, K, transpose=False)
+        C = torch.zeros(M, N, device=DEV); slot = torch.zeros(1, device=DEV)
+        ops.gemm_split_nt(M, N, K, A, K, sh, C, N, c_max=slot)
+        assert float(slot[0]) == float(C.abs().max()) > 0, (M, N, K)
+        slot.zero_()
+        ops.gemm_split_nt(M, N, K, A, K, sh, C, N, flags=ops.GEMM_RELU, c_max=slot)
+        assert float(slot[0]) == float(C.abs().max()) > 0, (M, N, K)
+        with pytest.raises((RuntimeError, ValueError)):
+            ops.gemm_split_nt(M, N, K, A, K, sh, C, N, flags=ops.GEMM_ATOMIC, splitk=2, c_max=slot)

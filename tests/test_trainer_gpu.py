@@ -9,7 +9,14 @@ import numpy as np
 import pytest
 import torch
 
+import margins
+
 pytestmark = pytest.mark.gpu
+
+# Bars of the end-to-end comparison (fp32-grade kernels vs the fp64 oracle).  SURVEY 8d words the loss bar as rel 1e-4;
+# a loss that is a mean of differences near zero needs an absolute term beside it.
+LOSS_ATOL, LOSS_RTOL = 2e-4, 2e-4
+GRAD_ATOL, GRAD_REL = 1e-5, 2e-4
 
 from oracle import maze as OM
 from oracle.trainer import OracleTrainer, ExplicitDraws
@@ -188,24 +195,32 @@ def test_process_matches_oracle(use_lstm, aux, n_vars):
         for key in ("policy_loss", "value_loss", "pc_loss", "vr_loss", "rp_loss", "total_loss"):
             if key in losses_o[0]:
                 want = np.mean([l[key] for l in losses_o])
-                assert abs(losses_dev[key] - want) <= 2e-4 + 2e-4 * abs(want), (it, key, losses_dev[key], want)
+                margins.record(key, abs(losses_dev[key] - want) / (LOSS_ATOL + LOSS_RTOL * abs(want)),
+                               "%g abs + %g rel" % (LOSS_ATOL, LOSS_RTOL), abs(losses_dev[key] - want) / (1e-4 * abs(want) + 1e-30))
+                assert abs(losses_dev[key] - want) <= LOSS_ATOL + LOSS_RTOL * abs(want), (it, key, losses_dev[key], want)
             else:
                 assert losses_dev[key] == 0.0, (key, losses_dev[key])          # a task that is off contributes nothing
         want_ent = np.mean([l["entropy"].sum() for l in losses_o])
-        assert abs(losses_dev["entropy"] - want_ent) <= 2e-4 + 2e-4 * abs(want_ent)
+        margins.record("entropy", abs(losses_dev["entropy"] - want_ent) / (LOSS_ATOL + LOSS_RTOL * abs(want_ent)),
+                       "%g abs + %g rel" % (LOSS_ATOL, LOSS_RTOL), abs(losses_dev["entropy"] - want_ent) / (1e-4 * abs(want_ent) + 1e-30))
+        assert abs(losses_dev["entropy"] - want_ent) <= LOSS_ATOL + LOSS_RTOL * abs(want_ent)
 
         # ---- gradients: per variable, |d| <= 1e-5 + 2e-4 * max|g_ref| ---------------------------
         for (name, _), gref in zip(orc.params.items(), mean_g):
             gr = gref.numpy().reshape(-1)
             gd = g_dev[name]
-            tol = 1e-5 + 2e-4 * np.abs(gr).max()
+            tol = GRAD_ATOL + GRAD_REL * np.abs(gr).max()
+            margins.record("g[%s]" % name, np.abs(gd - gr).max() / tol, "%g + %g of max |g|" % (GRAD_ATOL, GRAD_REL))
             assert np.abs(gd - gr).max() <= tol, (it, name, np.abs(gd - gr).max(), np.abs(gr).max())
+        margins.record("grad norm", abs(norm_dev - norm_o) / (1e-4 * max(1.0, norm_o)), "1e-4 rel")
         assert abs(norm_dev - norm_o) <= 1e-4 * max(1.0, norm_o), (norm_dev, norm_o)
 
         # ---- parameters after the update: |d| <= 2e-6 + 1e-5 rel --------------------------------
         for name, ref in orc.params.items():
             got = net.p[name].cpu().double().numpy()
             want = ref.numpy().reshape(-1)
+            margins.record("param %s after RMSProp" % name, np.abs(got - want).max() / (2e-6 + 1e-5 * np.abs(want).max()),
+                           "2e-6 + 1e-5 of max |p|")
             assert np.abs(got - want).max() <= 2e-6 + 1e-5 * np.abs(want).max(), (it, name)
         global_t += steps_dev
     assert all(len(e.seq_starts) == 0 and len(e.rp_u) == 0 for e in edraws)

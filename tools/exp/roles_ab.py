@@ -9,8 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SO = os.path.join(ROOT, "tools", "exp", "build", os.environ.get("ROLES_SO", "libenc_roles.so"))
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    sys.exit(subprocess.call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DUNREAL_ABLATE"] +
-                             os.environ.get("ROLES_FLAGS", "").split() + [os.path.join(ROOT, "unreal_amd/csrc/encoder.hip"), "-o", SO]))
+    sys.exit(subprocess.call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] +
+                             os.environ.get("ROLES_FLAGS", "").split() + [os.path.join(ROOT, "tools/exp/encoder_ablate.hip"), "-o", SO]))
 import torch
 N = int(os.environ.get("ABL_N", 81920))
 dev = "cuda:0"

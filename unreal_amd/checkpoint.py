@@ -11,38 +11,45 @@ SURVEY 5.4) and restarts them at rms = 1, momentum = 0; here they are saved too 
 False)` reproduces the reference's behaviour.  Replay, LSTM state and RNG are not saved (reference: neither)."""
 import glob
 import os
-import re
 import warnings
 
 import numpy as np
 import torch
 
 MAX_TO_KEEP = 20
-# prefix: anything (the caller's `name` may hold '-', digits or dots); the last two dash-separated fields are parsed
-_NAME = re.compile(r"^(?P<prefix>.+)-(?P<score>\d*)-(?P<t>\d+)\.pt$")
 
 
 def checkpoint_name(best_score, global_t, name=""):
+    """`<name>-<str(abs(best_score))[2:8]>-<global_t>.pt` (main.py:495-502).  The score field is whatever that slice
+    yields -- '123456' for -0.123456789, '.5' for 12.5, '0.0' for 100.0, '-05' for 1e-05 -- and is never parsed back."""
     base = name if name else "checkpoint"
     return "%s-%s-%d.pt" % (base, str(abs(float(best_score)))[2:8], int(global_t))
 
 
+def _parse_global_t(fn, base):
+    """global_t of `<base>-<anything>-<global_t>.pt`, parsed like the reference does (main.py:401-411: split on '-', take
+    the step token); None when the tail after the last '-' is not a step count (another run family, e.g.
+    'checkpoint-best-final.pt')."""
+    rest = fn[len(base) + 1:-len(".pt")]
+    if "-" not in rest:
+        return None
+    tail = rest.rsplit("-", 1)[1]
+    return int(tail) if tail.isdigit() else None
+
+
 def list_checkpoints(checkpoint_dir, name=""):
-    """[(global_t, path)] of the checkpoints called `name` (default "checkpoint"), sorted by global_t.  Files that do not
-    start with that name (best.pt, an exported model, another run's prefix) are not ours: they are left alone with a
-    warning, like the reference's Saver ignores unrelated files (main.py:356-427).  A file that DOES carry the prefix but
-    whose tail is not <score digits>-<global_t>.pt raises: it would be skipped by restore and by pruning alike."""
+    """[(global_t, path)] of the checkpoints called `name` (default "checkpoint"), sorted by global_t.  Anything else in the
+    directory (best.pt, an exported model, another prefix, a file of the prefix without a step count) is not ours: it is
+    left alone with a warning, like the reference, which only looks at what its Saver wrote (main.py:382-411)."""
     base = name if name else "checkpoint"
     out = []
     for p in sorted(glob.glob(os.path.join(checkpoint_dir, "*.pt"))):
         fn = os.path.basename(p)
-        if not fn.startswith(base + "-"):
-            warnings.warn("%s: not a '%s-*' checkpoint, ignored" % (p, base))
+        t = _parse_global_t(fn, base) if fn.startswith(base + "-") else None
+        if t is None:
+            warnings.warn("%s: not a '%s-<score>-<global_t>.pt' checkpoint, ignored" % (p, base))
             continue
-        m = _NAME.match(fn)
-        if m is None or m.group("prefix") != base:
-            raise ValueError("%s does not follow %s-<score digits>-<global_t>.pt" % (p, base))
-        out.append((int(m.group("t")), p))
+        out.append((t, p))
     return sorted(out)
 
 

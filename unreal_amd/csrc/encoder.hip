@@ -440,13 +440,21 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
     const int c = tid & 15;
     for (int k = tid >> 4; k < 192; k += 16) { const float w = fabsf(W1[k * 16 + c]); l1 += w; m1 = fmaxf(m1, w); }
     for (int e = tid; e < 8192; e += 256) m2 = fmaxf(m2, fabsf(W2[e]));
-    atomicAdd(red + c, l1);
+    // channel L1 norms in a FIXED order (a float atomicAdd's order is not: workgroups could then land on different sides
+    // of a power of two and round their c1 planes differently): the wave's four lanes of channel c by a shuffle tree, the
+    // four waves' partials by a fixed sum below.  (The maxima are order-independent: atomicMax.)
+    l1 += __shfl_xor(l1, 16, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    if (lane < 16) red[32 + gw * 16 + lane] = l1;
     atomicMax(reinterpret_cast<unsigned int*>(red + 16), __float_as_uint(m1));
     atomicMax(reinterpret_cast<unsigned int*>(red + 17), __float_as_uint(m2));
     __syncthreads();
     float bound = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) bound = fmaxf(bound, 255.f * fabsf(scale) * red[k] + fabsf(b1[k]));
+    for (int k = 0; k < 16; ++k) {
+      const float l1c = (red[32 + k] + red[48 + k]) + (red[64 + k] + red[80 + k]);
+      bound = fmaxf(bound, 255.f * fabsf(scale) * l1c + fabsf(b1[k]));
+    }
     S_W1 = pow2_scale(red[16]);
     S_W2 = pow2_scale(red[17]);
     S_C1 = pow2_scale(bound);
@@ -672,328 +680,9 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
   }
 }
 
-#ifdef UNREAL_ABLATE     // ---- round-2 backward kernel: kept as the A/B reference of tools/exp/roles_ab.py, not in the product ----
-// diagnostic stamps (tools/exp/ablate_encoder_bwd.py --stamps): where a wave's cycles go
-__device__ unsigned long long g_stamp_sum[4][16];
-#define STAMP(k)                                                                   \
-  do {                                                                             \
-    if (PHASES == 7 && blockIdx.x == 3 && lane == 0) {                             \
-      unsigned long long t_ = __builtin_amdgcn_s_memtime();                        \
-      g_stamp_sum[gw][k] += t_ - t_prev_;                                          \
-      t_prev_ = t_;                                                                \
-    }                                                                              \
-  } while (0)
-
-template <int PHASES>   // bit 0/1/2 = phase (1)/(2)/(3); 7 in the product, other values only for ablation timing
-__global__ __launch_bounds__(256, 2) void encoder_bwd_kernel(int N, const uint8_t* __restrict__ frames,
-                                                             const int* __restrict__ frame_idx, float scale,
-                                                             const float* __restrict__ W2,
-                                                             const float* __restrict__ c1_saved,
-                                                             const float* __restrict__ d2_in, float* __restrict__ dW1,
-                                                             float* __restrict__ db1, float* __restrict__ dW2,
-                                                             float* __restrict__ db2) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[BWD_LDS];
-  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  const int qq = i >> 2, pp = i & 3;       // transposed reads: lane 4qq + pp of a 16-lane group addresses block row qq
-  unsigned char* yp = smem;                 // uint8 frame (DMA) -> bf16 frame image
-  const unsigned lds_y = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-  unsigned char* zp = smem + Z_OFF;
-  unsigned char* xp = smem + X_OFF;
-  const unsigned char* xzero = xp + 3 * XPL;
-  if (tid < 16) reinterpret_cast<uint32_t*>(xp + 3 * XPL)[tid] = 0u;
-
-  // W2 fragments of phase (2), once per kernel: wave gw owns output parity (pa,pb) = (gw>>1, gw&1); tap dd = (da,db);
-  // A[row = c = i][k = n = 8q + j] = W2[pa+2da][pb+2db][c][n]
-  bf16x8 wa[4][3];
-#pragma unroll
-  for (int dd = 0; dd < 4; ++dd) {
-    const int ky = (gw >> 1) + 2 * (dd >> 1), kx = (gw & 1) + 2 * (dd & 1);
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(W2 + ((ky * 4 + kx) * 16 + i) * 32 + 8 * q);
-    u32x2v lo[3], hi[3];
-    split4(wsrc[0], lo);
-    split4(wsrc[1], hi);
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
-      wa[dd][t] = __builtin_bit_cast(bf16x8, w4);
-    }
-  }
-
-  f32x4 aw2[4][2];      // dW2 tiles: ky = gw, kx = 0..3, nt = 0..1
-  // dW1 tiles T = 0..11: patch elements m = 16T + row (a tile row = one (ky, kx, cin); 4 consecutive m are 8
-  // contiguous bytes of the bf16 frame image).  Wave gw owns the 6 tiles 6*(gw&1) + u over the positions
-  // [200*(gw>>1), +200) (half of K)
-  f32x4 aw1[6];
-  const int tset = gw & 1, khalf = gw >> 1;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) aw2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int a = 0; a < 6; ++a) aw1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float adb2[4] = {0.f, 0.f, 0.f, 0.f};   // n = (tid % 8) * 4 + e
-  float adb1[4] = {0.f, 0.f, 0.f, 0.f};   // channel 4q + e
-
-  int toff[6];          // byte offset (bf16 image) of patch elements 16T + 4pp .. +3 relative to the patch origin
-#pragma unroll
-  for (int u = 0; u < 6; ++u) {
-    const int m0 = 16 * (6 * tset + u) + 4 * pp;
-    toff[u] = ((m0 / 24) * FRAME_ROW_BYTES + (m0 % 24)) * 2;
-  }
-
-  const int stride = gridDim.x;
-  f32x4 pc1[C1_V], pd2[D2_V];
-  {
-    const int n0 = blockIdx.x;           // the launch guarantees gridDim.x <= N
-    const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)n0 * (C1_POS * C1_CH));
-#pragma unroll
-    for (int c = 0; c < C1_V; ++c) {
-      int id = tid + 256 * c;
-      pc1[c] = cs[id < C1_POS * 4 ? id : tid];
-    }
-    stage_c1_planes(xp, tid, pc1);
-    const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)n0 * F2_DIM);
-#pragma unroll
-    for (int c = 0; c < D2_V; ++c) {
-      int id = tid + 256 * c;
-      pd2[c] = ds[id < C2_POS * 8 ? id : tid];
-    }
-    stage_d2_planes(zp, tid, pd2, adb2);
-  }
-
-#ifdef UNREAL_ABLATE
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#ifdef UNREAL_EXP_KERNELS     // tools/exp/encoder_ablate.hip only: experiment kernels that need this file's helpers
+#include UNREAL_EXP_KERNELS
 #endif
-  int fidx = frame_idx[blockIdx.x];       // pool index of the frame, fetched one iteration ahead (a dependent scalar
-                                          // load in front of the DMA would expose an L2 round trip per frame)
-  for (int n = blockIdx.x; n < N; n += stride) {
-    const int nn = n + stride;
-    const bool has_next = nn < N;
-    STAMP(0);       // staging of this frame's planes (tail of the previous iteration) + loop overhead
-    {   // uint8 frame n -> FR by LDS-DMA (lane-linear 1 KiB pieces); first needed by phase (3)
-      const uint8_t* src = frames + (size_t)fidx * FRAME_BYTES;
-      for (int kk = gw; kk < FR_DMA; kk += 4) {
-        const int chunk = min(64 * kk + lane, FR_CHUNKS - 1);      // the overshoot of the last piece re-reads the last chunk
-        glds16(src + 16 * chunk, __builtin_amdgcn_readfirstlane(lds_y + 1024 * kk));
-      }
-    }
-    // an opaque 0, new every frame: added to the lane-dependent position indices below so that the address sets of
-    // the unrolled phases are NOT frame-invariant (hoisted out of the frame loop they occupy ~80 registers and spill)
-    int zero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-    STAMP(1);
-    WG_BARRIER();     // [S0] planes of frame n staged
-    STAMP(2);       // wait at S0
-    if (PHASES & 1) {
-      // (1) conv2 wgrad: dW2[(ky=gw,kx,c)][n] += sum_p c1[2oy+ky][2ox+kx][c] * d2[p][n]; K = 81 positions as 3 x 32
-#pragma unroll BWD_UNROLL_KS
-      for (int ks = 0; ks < 3; ++ks) {
-        const int p0 = 32 * ks + kdeal(q, qq) + zero, p1 = p0 + 8;        // <= 95: K padding reads the zero row 0
-        const int z0 = p0 < C2_POS ? (p0 / 9 + 1) * 10 + p0 % 9 + 1 : 0;
-        const int z1 = p1 < C2_POS ? (p1 / 9 + 1) * 10 + p1 % 9 + 1 : 0;
-        bf16x8 bf[2][3];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const unsigned char* b0 = zp + z0 * ZROW + ((4 * nt + pp) ^ (z0 & 4)) * 8;
-          const unsigned char* b1 = zp + z1 * ZROW + ((4 * nt + pp) ^ (z1 & 4)) * 8;
-#pragma unroll
-          for (int t = 0; t < 3; ++t) bf[nt][t] = tr_pair(b0 + t * ZPL, b1 + t * ZPL);
-        }
-        const int c0 = min(p0, C2_POS - 1), c1i = min(p1, C2_POS - 1);   // K padding: any valid c1 row (d2 row is 0)
-        const int r0 = (2 * (c0 / 9) + gw) * 20 + 2 * (c0 % 9), r1 = (2 * (c1i / 9) + gw) * 20 + 2 * (c1i % 9);
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-          const unsigned char* a0 = xp + xrow(r0 + kx) * XROW + 8 * pp;
-          const unsigned char* a1 = xp + xrow(r1 + kx) * XROW + 8 * pp;
-          bf16x8 af[3];
-#pragma unroll
-          for (int t = 0; t < 3; ++t) af[t] = tr_pair(a0 + t * XPL, a1 + t * XPL);
-          SPLIT_MMA(af, bf[0], aw2[kx][0]);
-          SPLIT_MMA(af, bf[1], aw2[kx][1]);
-        }
-      }
-    }
-    STAMP(3);       // phase 1
-    WG_BARRIER();     // [S1] all reads of the c1 planes done before d1 overwrites them
-    STAMP(4);       // wait at S1
-
-    if (PHASES & 2) {
-      // (2) conv2 dgrad, wave gw = output parity: d1^T[c][m] = sum_{dd,n} W2[pa+2da][pb+2db][c][n] * d2[a-da][b-db][n],
-      // m = 10a + b the position inside the parity (100 of them: 7 tiles of 16).  Tap (da,db) of position m is halo
-      // row m + 11 - (10da + db).
-      // software-pipelined: the three d2 fragments of the next tap (of the next tile after the last tap) are requested
-      // before the 6 MFMAs of the current one; two fragment sets alternate, sched_barrier pins the order
-      bf16x8 fa[3], fb[3];
-      auto load_tap = [&](int m, int dd, bf16x8 (&dst)[3]) {
-        const int r = m + 11 - 10 * (dd >> 1) - (dd & 1);
-        const unsigned char* zt = zp + r * ZROW + (q ^ ((r & 4) >> 1)) * 16;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(zt + pl * ZPL);
-      };
-      int m = min(i + zero, 99);
-      load_tap(m, 0, fa);
-#pragma unroll 1
-      for (int t = 0; t < 7; ++t) {
-        const int mn = min(16 * (t + 1) + i + zero, 99);           // next tile's position (unused after the last)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        load_tap(m, 1, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        SPLIT_MMA(wa[0], fa, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_tap(m, 2, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        SPLIT_MMA(wa[1], fb, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_tap(m, 3, fb);
-        __builtin_amdgcn_sched_barrier(0);
-        SPLIT_MMA(wa[2], fa, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load_tap(mn, 0, fa);
-        __builtin_amdgcn_sched_barrier(0);
-        SPLIT_MMA(wa[3], fb, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        const int ma = m / 10, mb = m - 10 * ma;
-        // acc[r] = d1 of channel 4q + r at position m: ReLU mask from the c1 hi terms it replaces, split, store
-        const int pos = (2 * ma + (gw >> 1)) * 20 + 2 * mb + (gw & 1);
-        unsigned char* dst = xp + xrow(pos) * XROW + 8 * q;
-        const u32x2v hi = *reinterpret_cast<const u32x2v*>(dst);
-        f32x4 g;
-        g[0] = (hi[0] & 0xffffu) ? acc[0] : 0.f;
-        g[1] = (hi[0] >> 16) ? acc[1] : 0.f;
-        g[2] = (hi[1] & 0xffffu) ? acc[2] : 0.f;
-        g[3] = (hi[1] >> 16) ? acc[3] : 0.f;
-        if (16 * t + i < 100) {
-          u32x2v pl[3];
-          split4(g, pl);
-#pragma unroll
-          for (int u = 0; u < 3; ++u) *reinterpret_cast<u32x2v*>(dst + u * XPL) = pl[u];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) adb1[e] += g[e];
-        }
-        m = mn;
-      }
-    }
-    STAMP(5);       // phase 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the frame have landed in FR
-    STAMP(6);       // wait for the frame DMA
-    WG_BARRIER();     // [S2] d1 planes complete; d2 planes dead; FR complete
-    STAMP(7);       // wait at S2
-
-    const int fidx_next = has_next ? frame_idx[nn] : 0;
-    if (has_next) {   // fetch the next frame's c1 and d2 behind phase (3)
-      const f32x4* cs = reinterpret_cast<const f32x4*>(c1_saved + (size_t)nn * (C1_POS * C1_CH));
-#pragma unroll
-      for (int c = 0; c < C1_V; ++c) {
-        int id = tid + 256 * c;
-        pc1[c] = cs[id < C1_POS * 4 ? id : tid];
-      }
-      const f32x4* ds = reinterpret_cast<const f32x4*>(d2_in + (size_t)nn * F2_DIM);
-#pragma unroll
-      for (int c = 0; c < D2_V; ++c) {
-        int id = tid + 256 * c;
-        pd2[c] = ds[id < C2_POS * 8 ? id : tid];
-      }
-    }
-    if (PHASES & 4) {
-      // uint8 frame -> bf16 image [84][252] over Y (a byte is exact in bf16): every thread takes its pieces into
-      // registers, then -- once all have -- writes them back twice as wide
-      u32x4 raw[FR_V];
-#pragma unroll
-      for (int k = 0; k < FR_V; ++k) raw[k] = *reinterpret_cast<const u32x4*>(yp + 16 * min(tid + 256 * k, FR_CHUNKS - 1));
-      STAMP(8);     // prefetch issue + FR reads
-      WG_BARRIER();   // [S2a] FR is in registers
-      STAMP(9);     // wait at S2a
-#pragma unroll
-      for (int k = 0; k < FR_V; ++k) {
-        const int c = tid + 256 * k;
-        if (c < FR_CHUNKS) {
-          u32x4 o[2];
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const uint32_t w = raw[k][d];
-            const float f0 = (float)(w & 0xffu), f1 = (float)((w >> 8) & 0xffu), f2 = (float)((w >> 16) & 0xffu),
-                        f3 = (float)(w >> 24);
-            o[d >> 1][2 * (d & 1)] = __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
-            o[d >> 1][2 * (d & 1) + 1] = __builtin_amdgcn_perm(__float_as_uint(f3), __float_as_uint(f2), 0x07060302u);
-          }
-          *reinterpret_cast<u32x4*>(yp + 32 * c) = o[0];
-          *reinterpret_cast<u32x4*>(yp + 32 * c + 16) = o[1];
-        }
-      }
-      STAMP(10);    // conversion + writes
-      WG_BARRIER();   // [S2b] bf16 frame image complete
-      STAMP(11);    // wait at S2b
-      // (3) conv1 wgrad: A = pixels (one exact bf16 term), B = the three d1 planes; BOTH through transposed reads
-      // (K = position).  Wave gw: positions [200*khalf, +200) as 7 chunks of 32 slots (24 of the last are zero
-      // padding) x its 6 row tiles.
-      const int pbase = 200 * khalf;
-#pragma unroll BWD_UNROLL_KC
-      for (int kc = 0; kc < 7; ++kc) {
-        const int s0 = 32 * kc + kdeal(q, qq) + zero, s1 = s0 + 8;
-        bf16x8 bpl[3];
-        {
-          const unsigned char* b0 = s0 < 200 ? xp + xrow(pbase + s0) * XROW + 8 * pp : xzero + 8 * pp;
-          const unsigned char* b1 = s1 < 200 ? xp + xrow(pbase + s1) * XROW + 8 * pp : xzero + 8 * pp;
-          const int po0 = s0 < 200 ? XPL : 0, po1 = s1 < 200 ? XPL : 0;
-#pragma unroll
-          for (int t = 0; t < 3; ++t) bpl[t] = tr_pair(b0 + t * po0, b1 + t * po1);
-        }
-        const int ps0 = pbase + min(s0, 199), ps1 = pbase + min(s1, 199);   // padding slots: any valid address (B = 0)
-        const unsigned char* a0 = yp + (4 * (ps0 / 20) * FRAME_ROW_BYTES + 12 * (ps0 % 20)) * 2;
-        const unsigned char* a1 = yp + (4 * (ps1 / 20) * FRAME_ROW_BYTES + 12 * (ps1 % 20)) * 2;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-          const bf16x8 av = tr_pair(a0 + toff[u], a1 + toff[u]);
-          aw1[u] = MFMA_BF16(av, bpl[2], aw1[u]);
-          aw1[u] = MFMA_BF16(av, bpl[1], aw1[u]);
-          aw1[u] = MFMA_BF16(av, bpl[0], aw1[u]);
-        }
-      }
-    }
-    STAMP(12);      // phase 3
-    WG_BARRIER();     // [S3] phase (3) finished reading the d1 planes and the frame image
-    STAMP(13);      // wait at S3
-    if (has_next) {
-      stage_c1_planes(xp, tid, pc1);
-      stage_d2_planes(zp, tid, pd2, adb2);
-    }
-    fidx = fidx_next;
-  }
-
-  // flush accumulators (C/D map of the 16x16 MFMAs: col = lane & 15, row = 4 * (lane >> 4) + r)
-#pragma unroll
-  for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(dW2 + ((gw * 4 + kx) * 16 + 4 * q + r) * 32 + nt * 16 + i, aw2[kx][nt][r]);
-#pragma unroll
-  for (int u = 0; u < 6; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW1 + (16 * (6 * tset + u) + 4 * q + r) * 16 + i, scale * aw1[u][r]);
-  // db1: lanes with equal q hold channels 4q..4q+3 (positions differ with i)
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v = adb1[e];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    if (i == 0) atomicAdd(db1 + 4 * q + e, v);
-  }
-  // db2: threads with equal (tid % 8) own the same 4 columns
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float v = adb2[e];
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    if (lane < 8) atomicAdd(db2 + lane * 4 + e, v);
-  }
-}
-#endif   // UNREAL_ABLATE (round-2 backward kernel)
 
 #include "encoder_bwd_roles.h"     // round 3: the role-specialised backward kernel (uses the helpers above)
 
@@ -1038,57 +727,8 @@ int exp_read_fstamps(unsigned long long* host32, int reset) {
   return 0;
 }
 #endif
-#ifdef UNREAL_ABLATE   // tools/exp only: never compiled into libunreal_hip.so
-int exp_encoder_bwd_roles(int variant, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
-                          const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
-                          float* db2, const float* c1_absmax, const float* d2_absmax, void* stream) {
-  int blocks = min(N, 256);             // one 512-thread workgroup per CU
-#define LAUNCH_R(P2C, P3ALL, ST) hipLaunchKernelGGL((encoder_bwd_roles_kernel<P2C, P3ALL, ST>), dim3(blocks), dim3(512), 0, \
-                                    (hipStream_t)stream, N, frames, frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2, c1_absmax, d2_absmax)
-  switch (variant) {
-    case 0: LAUNCH_R(7, true, false); break;
-    case 1: LAUNCH_R(6, true, false); break;
-    case 2: LAUNCH_R(5, true, false); break;
-    case 3: LAUNCH_R(7, false, false); break;
-    case 100: LAUNCH_R(7, true, true); break;
-    case 102: LAUNCH_R(5, true, true); break;
-    default: return UNREAL_EINVAL;
-  }
-  return unreal_launch_status();
-}
-int exp_read_rstamps(unsigned long long* host128, int reset) {
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(host128, HIP_SYMBOL(g_rstamp), sizeof(unsigned long long) * 128);
-  if (reset) {
-    unsigned long long z[128] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rstamp), z, sizeof(z));
-  }
-  return 0;
-}
-int exp_read_stamps(unsigned long long* host64, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_stamp_sum), sizeof(unsigned long long) * 64);
-  if (reset) {
-    unsigned long long z[64] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), z, sizeof(z));
-  }
-  return 0;
-}
-int exp_encoder_bwd_phases(int phases, int N, const uint8_t* frames, const int* frame_idx, float frame_scale,
-                           const float* W2, const float* c1_saved, const float* d2, float* dW1, float* db1, float* dW2,
-                           float* db2, void* stream) {
-  int blocks = min(N, 512);
-#define LAUNCH_(P) hipLaunchKernelGGL(encoder_bwd_kernel<P>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, \
-                                      frame_idx, frame_scale, W2, c1_saved, d2, dW1, db1, dW2, db2)
-  switch (phases) {
-    case 0: LAUNCH_(0); break;
-    case 1: LAUNCH_(1); break;
-    case 2: LAUNCH_(2); break;
-    case 4: LAUNCH_(4); break;
-    default: LAUNCH_(7); break;
-  }
-  return unreal_launch_status();
-}
+#ifdef UNREAL_EXP_ENTRIES     // tools/exp/encoder_ablate.hip only
+#include UNREAL_EXP_ENTRIES
 #endif
 
 }  // extern "C"

@@ -279,16 +279,8 @@ __device__ __forceinline__ void bwd_phase2_t(unsigned char* xp, const unsigned c
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     unsigned char* dst = xp;
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
-#ifdef EXP_P2_NOLOAD      // timing experiments only (results wrong)
-#define LT(a, b) do { if (t == T0) load_tap(a, b); } while (0)
-#else
 #define LT(a, b) load_tap(a, b)
-#endif
-#ifdef EXP_P2_NOEPI
-#define EPI_ON false
-#else
 #define EPI_ON true
-#endif
     LT(t, 3);
     SPLIT_MMA_OP(wa[0], f[0], acc);
     if (EPI_ON && t > T0) epi_mask(t - 1, prev, dst, g);
@@ -367,9 +359,7 @@ __device__ __forceinline__ void stage_c1_planes_r(unsigned char* xp, int tid, f3
     split4_op(pc1[c], scale, pl);
 #pragma unroll
     for (int t = 0; t < NPLB; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPLR + xoff(id >> 2, id & 3)) = pl[t];
-#ifndef EXP_NOLOAD_C1
     pc1[c] = reinterpret_cast<const f32x4*>(next)[id];
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -388,9 +378,7 @@ __device__ __forceinline__ void stage_d2_planes_r(unsigned char* zp, int tid, f3
     const float w = id0 < C2_POS * 8 ? count : 0.f;       // bias gradient: every element once, frames that exist only
 #pragma unroll
     for (int e = 0; e < 4; ++e) adb2[e] = fmaf(w, pd2[c][e], adb2[e]);
-#ifndef EXP_NOLOAD_D2
     pd2[c] = reinterpret_cast<const f32x4*>(next)[id];
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -419,9 +407,7 @@ __device__ __forceinline__ void build_image_r(unsigned char* ip, int tid, u32x4 
     }
     *reinterpret_cast<u32x4*>(ip + 32 * c) = o[0];
     *reinterpret_cast<u32x4*>(ip + 32 * c + 16) = o[1];
-#ifndef EXP_NOLOAD_U8
     raw[k] = reinterpret_cast<const u32x4*>(next)[c];
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -465,12 +451,18 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_roles_kernel(int N, const 
     float l1 = 0.f, mx = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { l1 += fabsf(w[j]); mx = fmaxf(mx, fabsf(w[j])); }
-    atomicAdd(red + c, l1);
+    // channel L1 norms in a FIXED order (float atomicAdd's is not: workgroups of one launch could pick different S_D1):
+    // the wave's four lanes of channel c by a shuffle tree, the eight waves' partials by a fixed sum
+    l1 += __shfl_xor(l1, 16, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    if (lane < 16) red[32 + wv * 16 + lane] = l1;
     atomicMax(reinterpret_cast<unsigned int*>(red + 16), __float_as_uint(mx));
     __syncthreads();
     float l1max = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) l1max = fmaxf(l1max, red[k]);
+    for (int k = 0; k < 16; ++k)
+      l1max = fmaxf(l1max, ((red[32 + k] + red[48 + k]) + (red[64 + k] + red[80 + k])) +
+                               ((red[96 + k] + red[112 + k]) + (red[128 + k] + red[144 + k])));
     const float d2m = *d2_absmax;
     S_C1 = pow2_scale(*c1_absmax);
     S_D2 = pow2_scale(d2m);

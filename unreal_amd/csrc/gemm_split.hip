@@ -940,6 +940,9 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   if ((flags & FLAG_ATOMIC) && (flags & (FLAG_RELU | FLAG_RELU_MASK | FLAG_RELU_BITS | FLAG_ACCUM))) return UNREAL_EINVAL;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !(flags & FLAG_ATOMIC)) return UNREAL_EINVAL;
+  // the atomic epilogue adds partial tiles into C: no workgroup ever sees a finished element, so max |C| cannot be
+  // committed there -- a slot left at 0 would silently turn the consumer's scale into 1
+  if ((flags & FLAG_ATOMIC) && c_absmax) return UNREAL_EINVAL;
   SplitArgs a;
   a.M = M; a.N = N; a.K = K;
   a.A = A; a.lda = lda; a.W = W3; a.ldw = ldw; a.plane = plane_stride; a.C = C; a.ldc = ldc;
@@ -948,7 +951,7 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   a.c_prev = nullptr; a.c_out = nullptr; a.h_out = nullptr; a.ld_h = 0;
   a.A2 = nullptr; a.lda2 = 0; a.K1 = K; a.K1pad = 0;
   a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
-  a.a_absmax = a_absmax; a.a_floor = 0.f; a.w_absmax = w_absmax; a.c_absmax0 = (flags & FLAG_ATOMIC) ? nullptr : c_absmax;
+  a.a_absmax = a_absmax; a.a_floor = 0.f; a.w_absmax = w_absmax; a.c_absmax0 = c_absmax;
   a.c_absmax1 = nullptr;
   {
     const int nk = (K + BK - 1) / BK;

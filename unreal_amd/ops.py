@@ -452,6 +452,9 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
     else:
         _chk(mask, "f32", (M - 1) * ldm + N if ldm else None, "mask", optional=True)
     _chk(a_max, "f32", 1, "a_max", optional=True); _chk(c_max, "f32", 1, "c_max", optional=True)
+    if c_max is not None and (flags & GEMM_ATOMIC):
+        raise ValueError("gemm_split_nt: the split-K / atomic epilogue cannot commit max |C| (c_max); reduce it with "
+                         "ops.absmax after the launch")
     if K < 64 and not (flags & GEMM_RELU_BITS):
         # one or two K tiles: nothing to split for -- hi + lo carries 22 bits per element, which only pays off against the
         # rounding of a long accumulation (at K = 3 the split result is ~2.5x the fp32 chain's error).  Such products (none
