@@ -158,15 +158,21 @@ def main():
     args = ap.parse_args()
 
     from unreal_amd import parallel
-    if args.gpus > 1 and "UNREAL_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
-        # (device_count() does not initialise the GPU: the launcher below stays a process that never touched it)
+    n_dev = parallel.visible_gpus()                    # from sysfs: the launcher below never initialises HIP / HSA
+    if args.gpus > 1 and "UNREAL_FORCE_DEVICE" not in os.environ and n_dev is not None and n_dev < args.gpus:
         raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s).  One rank per GPU over RCCL needs %d devices; "
                          "to rehearse several ranks on one device set UNREAL_FORCE_DEVICE=0 (gloo, not a measurement)."
-                         % (args.gpus, torch.cuda.device_count(), args.gpus))
+                         % (args.gpus, n_dev, args.gpus))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher only: nothing in this process has touched (or will touch) the GPU
         sys.exit(parallel.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     from unreal_amd import ops
+    if args.gpus > 1 and "UNREAL_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
+        # the authoritative check, in the RANK process (the sysfs count above sees the host's topology, which a container
+        # may show in full while exposing one device)
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s).  One rank per GPU over RCCL needs %d devices; "
+                         "to rehearse several ranks on one device set UNREAL_FORCE_DEVICE=0 (gloo, not a measurement)."
+                         % (args.gpus, torch.cuda.device_count(), args.gpus))
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -264,7 +270,7 @@ def main():
         "metric": "env-steps/sec (whole node), UNREAL maze 84x84",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic (device maze environments, random-init weights)",
+        "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA operands, fp32 accumulate)", "data": "synthetic (device maze environments, random-init weights)",
         "config": {"workload": "maze_environment full UNREAL (PC+RP+VR), %d batched actors per MI355X, "
                                "n_step_TD=%d, replay history %d/actor (uint8 HBM ring)" % (args.actors, T, args.history),
                    "actors_per_gpu": args.actors, "global_actors": args.actors * world,

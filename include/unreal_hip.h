@@ -48,7 +48,9 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
                              float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
                              float* episode_reward, float* score_out, int* score_valid, int* active,
                              int* active_log_t, int* n_steps, int* terminal_end, int* next_idx /*nullable*/,
-                             float* next_lar /*nullable*/, int lar_ld, int lar_col0, int A, void* stream);
+                             float* next_lar /*nullable*/, int lar_ld, int lar_col0, int A,
+                             int idx_base_actor /* next_idx[b] = (idx_base_actor + b) * H1 + slot: a half-batch whose
+                                                   rows index the whole ring */, void* stream);
 int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
                       const int* count, uint8_t* frames, void* stream);
 /* host-fed environments (environment/lab_environment.py:78-119 contract): `staged` holds one uint8

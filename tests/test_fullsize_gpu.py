@@ -160,8 +160,9 @@ def test_sampled_sequences_and_rp_triples(trained):
 #     reward-prediction logits;
 #   * the big backward kernels are re-launched on the LIVE full-size operands into fresh buffers and compared with an
 #     fp64 PyTorch evaluation of the same op on the device (test infrastructure: torch.matmul / conv in float64).
-# Tolerances: forward 2e-5 abs + 2e-5 rel (5e-5 after the 20-step LSTM), gradients 2e-4 of the largest element --
-# the bars of the small-shape tests.
+# Tolerances (round 4): forward = SURVEY 8d's 1e-5 abs + 1e-5 rel everywhere, also after the 20-step LSTM (rounds 1-3:
+# 2e-5 / 5e-5; measured worst 0.015 of the new bar); gradients 5e-5 of the largest element (rounds 1-3: 2e-4; measured
+# worst 0.21 of the new bar) -- profiles/r04_parity_margins.md.
 # ---------------------------------------------------------------------------------------------------------------------
 N_ACT = 64
 
@@ -176,7 +177,7 @@ def _close(got, ref, atol, rtol, what):
                                                                   ref.flat[np.argmax(err)], (got.shape,))
 
 
-def _close_grad(got, ref, what, rel=2e-4):
+def _close_grad(got, ref, what, rel=5e-5):
     got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = float(ref.abs().max())
@@ -206,8 +207,8 @@ def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what, btot=None):
     rows, x, lar = _actor_rows(ws, tr.ring, net, b, n, A, btot)
     _, h2 = M.encoder(x, p64)
     f = M.fc1(h2, p64)
-    _close(ws.f2.view(-1, 2592)[rows], h2.reshape(n, 2592), 2e-5, 2e-5, what + " conv2")
-    _close(ws.xcat.view(-1, ws.xld)[rows, :256], f, 2e-5, 2e-5, what + " fc")
+    _close(ws.f2.view(-1, 2592)[rows], h2.reshape(n, 2592), 1e-5, 1e-5, what + " conv2")
+    _close(ws.xcat.view(-1, ws.xld)[rows, :256], f, 1e-5, 1e-5, what + " fc")
     W, bias = p64["lstm_kernel"], p64["lstm_bias"]
     c, h = c0, h0
     cs, hs = [], []
@@ -218,8 +219,8 @@ def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what, btot=None):
         h = torch.tanh(c) * torch.sigmoid(o)
         cs.append(c); hs.append(h)
     cs, hs = torch.stack(cs), torch.stack(hs)
-    _close(ws.c.view(-1, 256)[rows], cs, 5e-5, 5e-5, what + " lstm c")
-    _close(ws.h.view(-1, 256)[rows], hs, 5e-5, 5e-5, what + " lstm h")
+    _close(ws.c.view(-1, 256)[rows], cs, 1e-5, 1e-5, what + " lstm c")
+    _close(ws.h.view(-1, 256)[rows], hs, 1e-5, 1e-5, what + " lstm h")
     return rows, hs
 
 
@@ -248,8 +249,8 @@ def test_fullshape_base_rows_match_oracle(branches):
         n = int(n_steps[b])
         rows, feat = _check_trunk(net, tr, ws, int(b), n, c0[b], h0[b], p64, "base actor %d" % b)
         pi, v = M.policy_value(feat, p64)
-        _close(tr.pi.view(-1, A)[rows], pi, 5e-5, 5e-5, "pi")
-        _close(tr.v[rows], v, 5e-5, 5e-5, "V")
+        _close(tr.pi.view(-1, A)[rows], pi, 1e-5, 1e-5, "pi")
+        _close(tr.v[rows], v, 1e-5, 1e-5, "V")
 
 
 def test_fullshape_backward_kernels_match_fp64(branches):
@@ -280,8 +281,8 @@ def test_fullshape_backward_kernels_match_fp64(branches):
         want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
         worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
         scale = max(scale, float(want.abs().max()))
-    margins.record("fc1 dgrad at %d rows" % rows, worst / (2e-4 * scale), "2e-4 of max |ref|")
-    assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad", worst, scale)
+    margins.record("fc1 dgrad at %d rows" % rows, worst / (5e-5 * scale), "5e-5 of max |ref|")
+    assert scale > 0 and worst <= 5e-5 * scale, ("fc1 dgrad", worst, scale)
     # conv encoder backward
     dW1, db1, dW2, db2 = z(3072), z(16), z(8192), z(32)
     ops.encoder_bwd(ring.frames, ws.frame_idx[:rows], net.frame_scale, p["W_base_conv2"], ws.c1, gws.d_f2, dW1, db1, dW2, db2)
@@ -358,8 +359,8 @@ def _check_lstm_backward(net, ws, gws, T_, Bt, d_feat, h0_nonzero, seqs, what):
         scale = max(scale, float(want.abs().max()))
         dc = dc * f
         dh_rec = want @ Wh.t()
-    margins.record(what + " d_gates of %d sequences (fp64 BPTT)" % n, worst / (2e-4 * scale), "2e-4 of max |d_gates|")
-    assert scale > 0 and worst <= 2e-4 * scale, (what, "d_gates", worst, scale)
+    margins.record(what + " d_gates of %d sequences (fp64 BPTT)" % n, worst / (5e-5 * scale), "5e-5 of max |d_gates|")
+    assert scale > 0 and worst <= 5e-5 * scale, (what, "d_gates", worst, scale)
 
 
 def test_fullshape_lstm_backward_matches_fp64(branches):
@@ -455,7 +456,7 @@ def test_fullshape_pixel_control_rows_match_oracle(branches):
             continue
         rows, feat = _check_trunk(net, tr, ws, int(b), n, z, z, p64, "pc actor %d" % b)
         hp = torch.relu(feat @ p64["W_pc_fc1"] + p64["b_pc_fc1"])
-        _close(gws.hp.view(-1, 2592)[rows], hp, 2e-5, 2e-5, "pc fc")
+        _close(gws.hp.view(-1, 2592)[rows], hp, 1e-5, 1e-5, "pc fc")
         h = hp.reshape(n, 9, 9, 32).permute(0, 3, 1, 2)
         v_pre = F.conv_transpose2d(h, Wv, p64["b_pc_deconv_v"], stride=2).detach().requires_grad_(True)
         a_pre = F.conv_transpose2d(h, Wa, p64["b_pc_deconv_a"], stride=2).detach().requires_grad_(True)
@@ -476,7 +477,7 @@ def test_fullshape_pixel_control_rows_match_oracle(branches):
     v = torch.relu(F.conv_transpose2d(h, Wv, p64["b_pc_deconv_v"], stride=2))
     a = torch.relu(F.conv_transpose2d(h, Wa, p64["b_pc_deconv_a"], stride=2))
     qmax = (v + a - a.mean(dim=1, keepdim=True)).max(dim=1)[0].reshape(-1, 400)
-    _close(tr.boot_qmax.view(B, 400)[torch.as_tensor(actors, device=DEV)], qmax, 2e-5, 2e-5, "bootstrap Q-max")
+    _close(tr.boot_qmax.view(B, 400)[torch.as_tensor(actors, device=DEV)], qmax, 1e-5, 1e-5, "bootstrap Q-max")
 
 
 def test_fullshape_value_replay_and_reward_prediction_rows_match_oracle(branches):
@@ -494,7 +495,7 @@ def test_fullshape_value_replay_and_reward_prediction_rows_match_oracle(branches
             continue
         rows, feat = _check_trunk(net, tr, ws, int(b), n, z, z, p64, "vr actor %d" % b)
         _, v = M.policy_value(feat, p64)
-        _close(tr.aux_v[rows], v, 5e-5, 5e-5, "value-replay V")
+        _close(tr.aux_v[rows], v, 1e-5, 1e-5, "value-replay V")
     rws = tr.rp_ws
     frames4 = tr.ring.frames.view(-1, 84, 84, 3)
     for b in actors:
@@ -502,7 +503,7 @@ def test_fullshape_value_replay_and_reward_prediction_rows_match_oracle(branches
         x = frames4[idx].cpu().double() * net.frame_scale
         _, h2 = M.encoder(x, p64)
         logits = h2.reshape(1, 7776) @ p64["W_rp_fc1"] + p64["b_rp_fc1"]
-        _close(tr.rp_logits.view(B, 3)[int(b)], logits.reshape(3), 2e-5, 2e-5, "rp logits")
+        _close(tr.rp_logits.view(B, 3)[int(b)], logits.reshape(3), 1e-5, 1e-5, "rp logits")
     l = tr.losses.cpu().numpy()
     assert np.isfinite(l).all() and l[3] > 0 and l[4] > 0 and l[5] > 0
 
@@ -532,10 +533,10 @@ def test_fullshape_batched_replay_pass_rows_match_oracle(branches):
             rows = torch.arange(n, device=DEV) * B + int(b)                 # the branch's own row numbering
             if s_ == 0:
                 hp = torch.relu(feat @ p64["W_pc_fc1"] + p64["b_pc_fc1"])
-                _close(gws.hp.view(-1, 2592)[rows], hp, 2e-5, 2e-5, "pc fc (batched pass)")
+                _close(gws.hp.view(-1, 2592)[rows], hp, 1e-5, 1e-5, "pc fc (batched pass)")
             else:
                 _, v = M.policy_value(feat, p64)
-                _close(tr.aux_v[rows], v, 5e-5, 5e-5, "value-replay V (batched pass)")
+                _close(tr.aux_v[rows], v, 1e-5, 1e-5, "value-replay V (batched pass)")
             checked += n
     assert checked > 32 * Ta
     l = tr.losses.cpu().numpy()
@@ -547,7 +548,7 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
     batched pass's contribution, its operands are live in aux2_ws / gws2): pixel-control deconv dgrad + wgrad on every
     other row of the 2B-sequence batch, the pc fc wgrad read through the doubled leading dimension, the 163,840-row fc1
     wgrad (split-K TN, K = 163,840) / dgrad and the 163,840-frame encoder_bwd -- each against an fp64 evaluation on the
-    device from the same live operands.  Tolerance: 2e-4 of the largest element, the bar of the small-shape tests."""
+    device from the same live operands.  Tolerance: 5e-5 of the largest element (rounds 1-3: 2e-4)."""
     import torch.nn.functional as F
     flags, net, tr, actors, p64 = branches
     if not tr.batch_aux:
@@ -576,8 +577,8 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
         scale = max(scale, float(want.abs().max()))
         r_dW += torch.einsum("nkp,ncp->kc", F.unfold(dd, 4, stride=2), h.reshape(n, 32, 81))
         r_db += dd.sum((0, 2, 3))
-    margins.record("pc deconv dgrad on every other row", worst / (2e-4 * scale), "2e-4 of max |ref|")
-    assert scale > 0 and worst <= 2e-4 * scale, ("pc deconv dgrad on every other row", worst, scale)
+    margins.record("pc deconv dgrad on every other row", worst / (5e-5 * scale), "5e-5 of max |ref|")
+    assert scale > 0 and worst <= 5e-5 * scale, ("pc deconv dgrad on every other row", worst, scale)
     r_dW = r_dW.view(1 + A, 4, 4, 32).permute(1, 2, 0, 3)                          # [ky,kx,o,c]
     _close_grad(g["W_pc_deconv_v"].view(4, 4, 1, 32), r_dW[:, :, :1], "g[W_pc_deconv_v]")
     _close_grad(g["W_pc_deconv_a"].view(4, 4, A, 32), r_dW[:, :, 1:], "g[W_pc_deconv_a]")
@@ -604,8 +605,8 @@ def test_fullshape_batched_replay_pass_backward_matches_fp64(branches):
         want = (d_fc[r0:r0 + 8192].double() @ Wd.t()) * (f2[r0:r0 + 8192] > 0)
         worst = max(worst, float((d_f2[r0:r0 + 8192].double() - want).abs().max()))
         scale = max(scale, float(want.abs().max()))
-    margins.record("fc1 dgrad at %d rows" % rows2, worst / (2e-4 * scale), "2e-4 of max |ref|")
-    assert scale > 0 and worst <= 2e-4 * scale, ("fc1 dgrad at %d rows" % rows2, worst, scale)
+    margins.record("fc1 dgrad at %d rows" % rows2, worst / (5e-5 * scale), "5e-5 of max |ref|")
+    assert scale > 0 and worst <= 5e-5 * scale, ("fc1 dgrad at %d rows" % rows2, worst, scale)
     # ---- conv encoder backward at 163,840 frames -----------------------------------------------------------------------
     W2 = net.params.shaped("W_base_conv2").double()
     w2_oihw = W2.permute(3, 2, 0, 1).contiguous()

@@ -2,7 +2,9 @@
 CPU oracle / a plain PyTorch fp32-or-fp64 reference on the same seeded inputs.
 
 Bars: integer / byte / index work bit-exact; floating point within the tolerance written at each
-assert (fp32 kernels vs an fp64 reference of the same op: abs 2e-5 + rel 2e-5 unless noted)."""
+assert (fp32-grade kernels vs an fp64 reference of the same op: SURVEY 8d's forward bar, abs 1e-5 + rel 1e-5, unless
+noted; sums over K >> 1 terms of O(1) magnitude carry an absolute term that grows with K).  Measured margins:
+profiles/r04_parity_margins.md."""
 import os
 
 import numpy as np
@@ -37,7 +39,7 @@ def dev(a, dt=None):
     return t.to(DEV).contiguous()
 
 
-def close(got, ref, atol=2e-5, rtol=2e-5, what=""):
+def close(got, ref, atol=1e-5, rtol=1e-5, what=""):
     got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, dtype=np.float64)
     ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
     err = np.abs(got - ref) - (atol + rtol * np.abs(ref))
@@ -352,7 +354,7 @@ def test_gemm_variants(ops, ta, tb, M, N, K):
     Aop = (A[:, :M].T if ta else A[:, :K])
     Bop = (B[:, :K].T if tb else B[:, :N])
     ref = Aop @ Bop
-    tol = dict(atol=3e-7 * K, rtol=1e-5)
+    tol = dict(atol=1e-7 * K, rtol=1e-5)      # (rounds 1-3: 3e-7 * K; measured worst 0.12 of that)
     C = torch.full((M, ldc), 7.0, device=DEV)
     ops.gemm(ta, tb, M, N, K, dev(A, torch.float32), lda, dev(B, torch.float32), ldb, C, ldc, bias=dev(bias, torch.float32))
     close(C[:, :N], ref + bias, what="bias", **tol)
@@ -495,8 +497,8 @@ def test_lstm_gates_fwd_bwd(ops):
     dcio = dev(dc.reshape(-1), torch.float32)
     ops.lstm_gates_bwd(rows, dev(dh.reshape(-1), torch.float32), dev(dhr.reshape(-1), torch.float32), dcio, ga,
                        dev(c0.detach().reshape(-1), torch.float32), co, dpre)
-    close(dpre.reshape(rows, 1024), pre.grad, what="dpre", atol=5e-5, rtol=1e-4)
-    close(dcio.reshape(rows, 256), c0.grad, what="dc_prev", atol=5e-5, rtol=1e-4)
+    close(dpre.reshape(rows, 1024), pre.grad, what="dpre")
+    close(dcio.reshape(rows, 256), c0.grad, what="dc_prev")
 
 
 @pytest.mark.parametrize("rows,K,NOUT", [(37, 256, 4), (37, 256, 1), (300, 7776, 3), (5, 256, 6)])
@@ -512,14 +514,14 @@ def test_linear_small(ops, rows, K, NOUT):
     o = torch.zeros(rows * NOUT, device=DEV)
     ops.linear_small_fwd(rows, K, NOUT, dev(X.detach().reshape(-1), torch.float32), ldx,
                          dev(W.detach().reshape(-1), torch.float32), dev(b.detach(), torch.float32), o, NOUT)
-    close(o.reshape(rows, NOUT), out, what="fwd", atol=1e-4, rtol=1e-4)
+    close(o.reshape(rows, NOUT), out, what="fwd")
     dX0 = rs.normal(size=(rows, K))
     dX = dev(dX0.reshape(-1), torch.float32)
     dW = torch.zeros(K * NOUT, device=DEV); db = torch.zeros(NOUT, device=DEV)
     ops.linear_small_bwd(rows, K, NOUT, dev(X.detach().reshape(-1), torch.float32), ldx,
                          dev(dO.reshape(-1), torch.float32), NOUT, dev(W.detach().reshape(-1), torch.float32), dX, K,
                          True, dW, db)
-    close(dX.reshape(rows, K), X.grad[:, :K] + dX0, what="dX", atol=1e-4, rtol=1e-4)
+    close(dX.reshape(rows, K), X.grad[:, :K] + dX0, what="dX")
     close(dW.reshape(K, NOUT), W.grad, what="dW", atol=2e-4, rtol=1e-4)
     close(db, b.grad, what="db", atol=2e-4, rtol=1e-4)
 
@@ -652,7 +654,7 @@ def test_pc_deconv_fwd_bwd(ops, N, A):
     dWv = torch.zeros(512, device=DEV); dbv = torch.zeros(1, device=DEV)
     dWa = torch.zeros(512 * A, device=DEV); dba = torch.zeros(A, device=DEV)
     ops.pc_deconv_bwd(N, A, d["hp"], d_dec, d["Wv"], d["Wa"], d_hp, dWv, dbv, dWa, dba)
-    tol = dict(atol=2e-5, rtol=1e-4)
+    tol = dict(atol=1e-5, rtol=1e-5)
     close(d_hp.reshape(N, 9, 9, 32), hp.grad * (hp.detach() > 0), what="d_hp", **tol)
     close(dWv.reshape(4, 4, 1, 32), Wv.grad, what="dWv", **tol)
     close(dWa.reshape(4, 4, A, 32), Wa.grad, what="dWa", **tol)

@@ -13,10 +13,15 @@ import margins
 
 pytestmark = pytest.mark.gpu
 
-# Bars of the end-to-end comparison (fp32-grade kernels vs the fp64 oracle).  SURVEY 8d words the loss bar as rel 1e-4;
-# a loss that is a mean of differences near zero needs an absolute term beside it.
-LOSS_ATOL, LOSS_RTOL = 2e-4, 2e-4
-GRAD_ATOL, GRAD_REL = 1e-5, 2e-4
+# Bars of the end-to-end comparison (fp32-grade kernels vs the fp64 oracle).  Losses: SURVEY 8d's rel 1e-4 (rounds 1-3:
+# 2e-4 abs + 2e-4 rel; the absolute term only guards a loss that is exactly 0).  Gradients: SURVEY names no bar; 2e-5 of
+# the variable's largest element (rounds 1-3: 2e-4).  Measured worst |error| / bar over the seven flag sets on MI355X:
+# losses 0.06, gradients 0.04 (profiles/r04_parity_margins.md).
+LOSS_ATOL, LOSS_RTOL = 1e-6, 1e-4
+GRAD_ATOL, GRAD_REL = 1e-6, 2e-5
+# host-fed actors (uint8 observations / 255, raw rewards): the bars of rounds 1-3, margins recorded since round 4
+HF_LOSS_ATOL, HF_LOSS_RTOL = 3e-4, 3e-4
+HF_GRAD_ATOL, HF_GRAD_REL = 1e-5, 3e-4
 
 from oracle import maze as OM
 from oracle.trainer import OracleTrainer, ExplicitDraws
@@ -191,7 +196,7 @@ def test_process_matches_oracle(use_lstm, aux, n_vars):
         if it == 1:
             assert episodes_dev >= 1, "teleported actors should finish an episode (ragged rollout is covered)"
 
-        # ---- losses: mean over actors of the per-actor sums; |d| <= 2e-4 abs + 2e-4 rel ----------
+        # ---- losses: mean over actors of the per-actor sums; SURVEY 8d: rel 1e-4 --------------------
         for key in ("policy_loss", "value_loss", "pc_loss", "vr_loss", "rp_loss", "total_loss"):
             if key in losses_o[0]:
                 want = np.mean([l[key] for l in losses_o])
@@ -205,7 +210,7 @@ def test_process_matches_oracle(use_lstm, aux, n_vars):
                        "%g abs + %g rel" % (LOSS_ATOL, LOSS_RTOL), abs(losses_dev["entropy"] - want_ent) / (1e-4 * abs(want_ent) + 1e-30))
         assert abs(losses_dev["entropy"] - want_ent) <= LOSS_ATOL + LOSS_RTOL * abs(want_ent)
 
-        # ---- gradients: per variable, |d| <= 1e-5 + 2e-4 * max|g_ref| ---------------------------
+        # ---- gradients: per variable, |d| <= 1e-6 + 2e-5 * max|g_ref| ---------------------------
         for (name, _), gref in zip(orc.params.items(), mean_g):
             gr = gref.numpy().reshape(-1)
             gd = g_dev[name]
@@ -299,12 +304,13 @@ def test_batch1_runners_match_oracle():
         v_only = net.run_base_value(None, env.last_state, lar)
         pi, v, _ = net.run_base_policy_and_value(None, env.last_state, lar)
         np.testing.assert_allclose(pi, pi_o[0].numpy(), atol=2e-6, rtol=1e-5)
-        assert abs(v - float(v_o[0])) < 2e-5 and abs(v_only - float(v_o[0])) < 2e-5
+        margins.record("batch-1 V", max(abs(v - float(v_o[0])), abs(v_only - float(v_o[0]))) / 1e-5, "1e-5 abs")
+        assert abs(v - float(v_o[0])) < 1e-5 and abs(v_only - float(v_o[0])) < 1e-5
         fz, _ = M.trunk(x, tl, p, True, None)
         _, qm = M.pc_head(fz, p)
-        np.testing.assert_allclose(net.run_pc_q_max(None, env.last_state, lar), qm[0].numpy(), atol=2e-5, rtol=2e-5)
+        np.testing.assert_allclose(net.run_pc_q_max(None, env.last_state, lar), qm[0].numpy(), atol=1e-5, rtol=1e-5)
         _, vz = M.policy_value(fz, p)
-        assert abs(net.run_vr_value(None, env.last_state, lar) - float(vz[0])) < 2e-5
+        assert abs(net.run_vr_value(None, env.last_state, lar) - float(vz[0])) < 1e-5
         state = st
         env.process(int(rs.randint(4)))
     hist = [{'image': OM.render(0, 2)}, {'image': OM.render(1, 2)}, {'image': OM.render(1, 3)}]
@@ -389,11 +395,15 @@ def _hostfed_parity(cfg, B, H, T, tr, net, applier, draws, orc, edraws, check_fr
                 assert losses_dev[key] == 0.0
                 continue
             want = np.mean([l[key] for l in losses_o])
-            assert abs(losses_dev[key] - want) <= 3e-4 + 3e-4 * abs(want), (it, key, losses_dev[key], want)
+            margins.record("host-fed " + key, abs(losses_dev[key] - want) / (HF_LOSS_ATOL + HF_LOSS_RTOL * abs(want)),
+                           "%g abs + %g rel" % (HF_LOSS_ATOL, HF_LOSS_RTOL), abs(losses_dev[key] - want) / (1e-4 * abs(want) + 1e-30))
+            assert abs(losses_dev[key] - want) <= HF_LOSS_ATOL + HF_LOSS_RTOL * abs(want), (it, key, losses_dev[key], want)
         for (name, _), gref in zip(orc.params.items(), mean_g):
             gr = gref.numpy().reshape(-1)
-            tol = 1e-5 + 3e-4 * np.abs(gr).max()
+            tol = HF_GRAD_ATOL + HF_GRAD_REL * np.abs(gr).max()
+            margins.record("host-fed g[%s]" % name, np.abs(g_dev[name] - gr).max() / tol, "%g + %g of max |g|" % (HF_GRAD_ATOL, HF_GRAD_REL))
             assert np.abs(g_dev[name] - gr).max() <= tol, (it, name, np.abs(g_dev[name] - gr).max(), np.abs(gr).max())
+        margins.record("host-fed grad norm", abs(norm_dev - norm_o) / (2e-4 * max(1.0, norm_o)), "2e-4 rel")
         assert abs(norm_dev - norm_o) <= 2e-4 * max(1.0, norm_o)
         global_t += steps_dev
 
@@ -513,3 +523,44 @@ def test_config1_long_horizon_drift_is_fp32_grade():
         assert pd_dev <= 4.0 * max(pd_o32, 1e-7) + 1e-7, (it, pd_dev, pd_o32)
         g_t += steps
     assert worst_dev < 5e-2
+
+
+@pytest.mark.parametrize("use_lstm,groups", [(True, 1), (False, 1), (True, 2)])
+def test_half_batch_rollout_on_two_streams_is_the_lockstep_rollout(use_lstm, groups, monkeypatch):
+    """Trainer._rollout_steps_split (maze actors: the T rollout steps as two half-batches on their own HIP streams) runs the
+    same kernels on the same rows with the same draws as the lock-step loop: after the replay fill and three updates,
+    every rollout product (actions, rewards, terminals, step counts, frame indices, pi, V, carried LSTM state) is
+    IDENTICAL, and losses / parameters agree to the last bits (a half's GEMMs may run under the running maximum of its
+    own rows instead of all actors': the same power-of-two scale unless the two straddle a binade)."""
+    from unreal_amd.train.trainer import Trainer
+    B, H, T = 64, 40, 20
+    cfg = _cfg(use_lstm, True, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    out = []
+    for parts in (0, 2):
+        monkeypatch.setattr(Trainer, "rollout_parts_default", parts)
+        monkeypatch.setattr(Trainer, "ROLLOUT_SPLIT_MIN_ACTORS", 2)
+        net, applier, tr, draws = _build(cfg, B, seed=5, groups=groups)
+        assert (tr._split is not None) == (parts == 2)
+        while not tr._full:
+            tr.process(None, 0)
+        g = 0
+        snaps = []
+        for it in range(3):
+            steps, _ = tr.process(None, g)
+            g += steps
+            snaps.append(dict(actions=tr.actions.cpu().numpy().copy(), rewards=tr.rewards.cpu().numpy().copy(),
+                              terminals=tr.terminals.cpu().numpy().copy(), n_steps=tr.n_steps.cpu().numpy().copy(),
+                              idx=tr.base_ws.frame_idx.cpu().numpy().copy(), pi=tr.pi.cpu().numpy().copy(),
+                              v=tr.v.cpu().numpy().copy(), c=tr.full_lstm_c.cpu().numpy().copy(),
+                              steps=steps, losses=dict(tr.last_losses), params=net.params.flat.cpu().numpy().copy()))
+        out.append(snaps)
+    for a, b in zip(*out):
+        for k in ("actions", "rewards", "terminals", "n_steps", "idx"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        assert a["steps"] == b["steps"]
+        for k in ("pi", "v", "c"):
+            np.testing.assert_allclose(b[k], a[k], rtol=2e-6, atol=2e-7, err_msg=k)
+        for k in ("total_loss", "pc_loss", "vr_loss", "rp_loss", "grad_norm"):
+            assert abs(a["losses"][k] - b["losses"][k]) <= 1e-5 * max(1.0, abs(a["losses"][k])), k
+        np.testing.assert_allclose(b["params"], a["params"], rtol=1e-5, atol=1e-7)

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = {"base": [], "deep128": ["-DSPLIT_NT_DEEP128=1"]}
+VARIANTS = {"base": [], "dbuf": ["-DSPLIT_NT_DBUF=1"]}      # round 3 also timed deep128 = -DSPLIT_NT_DEEP128=1
 # earlier rounds of this script (results in profiles/r03_gemm_nt_ablate.log): timing-only ablations "nosplit" / "noload" /
 # "nosplit_noload" = -DSPLIT_ABLATE=2 / 1 / 3 (pass them as name=-DFLAG on the command line); the direct-store epilogue
 # and the 128 x 256 tile variants were removed from the kernel after they lost
@@ -55,6 +55,9 @@ SHAPES = [  # name, M, N, K, flags
     ("fc1 fwd    163840 x 256 x 2592 (bias, relu)", 163840, 256, 2592, "relu"),
     ("lstm dgrad  81920 x 256 x 1024", 81920, 256, 1024, ""),
     ("pc_fc1 dgrad 81920 x 256 x 2592", 81920, 256, 2592, ""),
+    ("fc rollout   4096 x 256 x 2592 (bias, relu)", 4096, 256, 2592, "relu"),
+    ("fc group      512 x 256 x 2592 (bias, relu)", 512, 256, 2592, "relu"),
+    ("bptt-shaped  4096 x 256 x 1024", 4096, 256, 1024, ""),
 ]
 for name, M, N, K, fl in SHAPES:
     A = torch.randn(M * K, device=dev)

@@ -61,6 +61,17 @@ __device__ __forceinline__ float pow2_scale(float m) {
 }
 __device__ __forceinline__ float pow2_inv(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }
 
+// ReLU masks are read from the hi PLANE of a non-negative activation (conv1 output in unreal_encoder_bwd, the
+// pixel-control fc output in unreal_pc_deconv_bwd: "hi != 0 <=> x > 0").  A positive x below 2^-39 of the tensor maximum
+// rounds to fp16 zero under the tensor's scale and would be masked out -- an error of the size of the whole gradient
+// element, not of x.  So the hi halfword of a positive x is kept at least at the smallest fp16 subnormal (2^-24 in scaled
+// units: under 2^-38 of the tensor maximum, inside the format's own absolute floor).  hi_pair = two fp16 of x0, x1 >= 0.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int keep_positive_visible(unsigned int hi_pair, float x0, float x1) {
+  const u16x2_t f = {(unsigned short)(x0 > 0.f ? 1 : 0), (unsigned short)(x1 > 0.f ? 1 : 0)};
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, hi_pair), f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

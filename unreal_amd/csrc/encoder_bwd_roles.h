@@ -251,8 +251,8 @@ __device__ __forceinline__ void bwd_phase2_t(unsigned char* xp, const unsigned c
     PIN(T.dst[t]);
     dst = xp + LO16(T.dst[t]);
     const u32x2v hi = *reinterpret_cast<const u32x2v*>(dst);
-    // ReLU mask from the c1 hi term (fp16x2: a positive c1 below 2^-39 of the tensor's maximum has hi = 0 and is treated as
-    // not active: ~1e-12 per element).  (The dump row's "hi" is whatever was dumped last: harmless.)
+    // ReLU mask from the c1 hi term: the producers keep the hi halfword of every positive c1 non-zero, however small
+    // (keep_positive_visible), so "hi != 0" IS c1 > 0.  (The dump row's "hi" is whatever was dumped last: harmless.)
     g[0] = (hi[0] & 0xffffu) ? acc[0] * acc_scale : 0.f;
     g[1] = (hi[0] >> 16) ? acc[1] * acc_scale : 0.f;
     g[2] = (hi[1] & 0xffffu) ? acc[2] * acc_scale : 0.f;
@@ -357,6 +357,10 @@ __device__ __forceinline__ void stage_c1_planes_r(unsigned char* xp, int tid, f3
     const int id0 = tid + 256 * c, id = id0 < C1_POS * 4 ? id0 : tid;
     u32x2v pl[3];
     split4_op(pc1[c], scale, pl);
+#if ENC_BWD_F16      // c1 = relu(...) >= 0: the dgrad epilogue's ReLU mask reads "hi != 0" (common.h: keep_positive_visible)
+    pl[0][0] = keep_positive_visible(pl[0][0], pc1[c][0], pc1[c][1]);
+    pl[0][1] = keep_positive_visible(pl[0][1], pc1[c][2], pc1[c][3]);
+#endif
 #pragma unroll
     for (int t = 0; t < NPLB; ++t) *reinterpret_cast<u32x2v*>(xp + t * XPLR + xoff(id >> 2, id & 3)) = pl[t];
     pc1[c] = reinterpret_cast<const f32x4*>(next)[id];

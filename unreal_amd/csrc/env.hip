@@ -125,9 +125,10 @@ struct StepArgs {
   int* active_log_t;     // active flag of this step (row mask of the losses)
   int* n_steps;          // += 1 per step taken
   int* terminal_end;     // set at the terminal
-  int* next_idx;         // nullable: ring index of the NEXT observation (b * H1 + slot), also for idle actors
+  int* next_idx;         // nullable: ring index of the NEXT observation ((idx_base + b) * H1 + slot), also for idle actors
   float* next_lar;       // nullable: [B][lar_ld] rows of the next step's LSTM input: one-hot last action | last reward
   int lar_ld, lar_col0, A;
+  int idx_base;          // index of this launch's first actor in the ring next_idx is meant for (a half-batch of a ring)
 };
 
 // APG actors per workgroup: 8 when the batch fills the chip (the wall image is built once per workgroup: ~2.5 us of VALU),
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
     if (!act_flag) {
       // idle for the rest of the rollout: its observation and last action / reward stay what they are
       if (threadIdx.x == 0) {
-        if (p.next_idx) p.next_idx[b] = b * H1 + s_cnt[k] % H1;
+        if (p.next_idx) p.next_idx[b] = (p.idx_base + b) * H1 + s_cnt[k] % H1;
         if (p.next_lar) {
           float* row = p.next_lar + (size_t)b * p.lar_ld + p.lar_col0;
           const int la0 = s_la[k];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
           p.terminal_end[b] = 1;
         }
       }
-      if (p.next_idx) p.next_idx[b] = b * H1 + nslot;
+      if (p.next_idx) p.next_idx[b] = (p.idx_base + b) * H1 + nslot;
       if (p.next_lar) {
         float* row = p.next_lar + (size_t)b * p.lar_ld + p.lar_col0;
         const int la1 = reset ? 0 : a;
@@ -482,7 +483,7 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
   StepArgs p{B, H1, actions, active, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
-             nullptr, 0, 0, 0};
+             nullptr, 0, 0, 0, 0};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
@@ -493,15 +494,16 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
                              float* r_last_reward, float* r_pc, float* out_reward, int* out_terminal,
                              float* episode_reward, float* score_out, int* score_valid, int* active,
                              int* active_log_t, int* n_steps, int* terminal_end, int* next_idx, float* next_lar,
-                             int lar_ld, int lar_col0, int A, void* stream) {
+                             int lar_ld, int lar_col0, int A, int idx_base_actor, void* stream) {
   if (B <= 0 || H1 < 2 || !actions || !pos || !count || !frames || !last_action || !last_reward) return UNREAL_EINVAL;
   if (!episode_reward || !score_out || !score_valid || !active || !active_log_t || !n_steps || !terminal_end)
     return UNREAL_EINVAL;
   if (next_lar && (A <= 0 || lar_col0 < 0 || lar_ld < lar_col0 + A + 1)) return UNREAL_EINVAL;
+  if (idx_base_actor < 0) return UNREAL_EINVAL;
   StepArgs p{B, H1, actions, nullptr, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
-             lar_col0, A};
+             lar_col0, A, idx_base_actor};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();

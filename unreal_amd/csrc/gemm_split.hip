@@ -64,6 +64,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                             // 8 every block reads the same 8 rows of A (cache hits)
 #endif
 
+#ifndef SPLIT_NT_DBUF
+#define SPLIT_NT_DBUF 0     // 1: two LDS operand images, one barrier per K tile (tools/exp/gemm_ab.py)
+#endif
 #ifndef SPLIT_ROW_DEAL
 #define SPLIT_ROW_DEAL 1    // 0: tile rows in lane order (tools/exp/ab_split_rows.py times both)
 #endif
@@ -299,7 +302,14 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     INV_W = pow2_inv(pow2_scale(*p.w_absmax));
   }
   constexpr int C_BYTES = BM * (BN + 4) * 4;
-  constexpr int SMEM = (A_BYTES + B_BYTES) > C_BYTES ? (A_BYTES + B_BYTES) : C_BYTES;
+  // DBUF: two operand images -- tile it + 1 is split / stored into the other one while tile it is multiplied, so a K tile
+  // costs ONE workgroup barrier (stores visible) instead of two (all reads done; stores visible).  128 x 128: 2 x 40,960 B
+  // per workgroup, two workgroups per CU use the 160 KB exactly.
+  constexpr int NBUF = SPLIT_NT_DBUF ? 2 : 1;
+  constexpr int OP_BYTES = A_BYTES + B_BYTES;
+  constexpr int RED_BYTES = 64;                  // the epilogues' per-wave maxima (absmax commits) live behind the C tile
+  constexpr int SMEM = (NBUF * OP_BYTES) > (C_BYTES + RED_BYTES) ? (NBUF * OP_BYTES) : (C_BYTES + RED_BYTES);
+  static_assert(4 * KW * 4 <= RED_BYTES, "one float per wave");
   __shared__ __attribute__((aligned(16))) unsigned char smem_all[KW * SMEM];
 #ifdef SPLIT_STAMPS
   unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
@@ -396,7 +406,45 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     if (!(SPLIT_ABLATE & 4)) mma_frags<TM, TN>(af, bf, acc);                                                        \
     __syncthreads();                                   /* tile IT + 1 is visible */                                 \
   }
-  if (DEEP) {
+  // DBUF form of one K tile: fragments of tile IT come from image IT & 1; tile IT + 1 goes into the other image at any
+  // point of the step (everybody left that image before the previous step's barrier), so the split VALU, the LDS stores
+  // and the next global loads spread over all 24 MFMAs; the one barrier sits before the second half's MFMAs, which then
+  // run while the slower waves arrive.
+#define SPLIT_NT_TILE_DB(S, IT)                                                                                     \
+  {                                                                                                                 \
+    frag8 af[TM][NPL], bf[TN][NPL];                                                                                  \
+    const unsigned char* Ac = As + ((IT) & 1) * OP_BYTES;                                                           \
+    const unsigned char* Bc = Bs + ((IT) & 1) * OP_BYTES;                                                           \
+    unsigned char* An = As + (((IT) + 1) & 1) * OP_BYTES;                                                           \
+    unsigned char* Bn = Bs + (((IT) + 1) & 1) * OP_BYTES;                                                           \
+    read_frags<BM, BN, MODE>(Ac, Bc, wm, wn, li, kh, 0, af, bf);                                                    \
+    const int kcur = KG_AT((IT) + 1), kw = KG_AT((IT) + 2), ka = KG_AT((IT) + (DEEP ? 3 : 2));                      \
+    const ASrc<DUAL> scur = a_src<DUAL>(p, kcur), snext = a_src<DUAL>(p, ka);                                       \
+    const int klim = KLIM((IT) + 1, scur);                                                                          \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
+      a_piece_store<BM, MODE>(An, ra[S][q], klim, q, tid, SA);                                                      \
+      ra[S][q] = A_LOAD(snext, q);                                                                                  \
+    }                                                                                                               \
+    _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
+      w_piece_store<BN>(Bn, rw[q], q, tid);                                                                         \
+      rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, kw, q, tid);                                           \
+    }                                                                                                               \
+    mma_frags<TM, TN>(af, bf, acc);                                                                                 \
+    read_frags<BM, BN, MODE>(Ac, Bc, wm, wn, li, kh, 1, af, bf);                                                    \
+    __syncthreads();                                   /* tile IT + 1 is visible; everybody has read tile IT */      \
+    mma_frags<TM, TN>(af, bf, acc);                                                                                 \
+  }
+  if (SPLIT_NT_DBUF) {
+    if (DEEP) {
+      for (int it = 0; it < nit; it += 2) {
+        SPLIT_NT_TILE_DB(0, it)
+        if (it + 1 < nit) SPLIT_NT_TILE_DB(1, it + 1)
+      }
+    } else {
+      for (int it = 0; it < nit; ++it) SPLIT_NT_TILE_DB(0, it)
+    }
+    __syncthreads();     // the epilogue parks its tile over the operand images: every wave must have read the last one
+  } else if (DEEP) {
     for (int it = 0; it < nit; it += 2) {
       SPLIT_NT_TILE(0, it)
       if (it + 1 < nit) SPLIT_NT_TILE(1, it + 1)
@@ -405,6 +453,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     for (int it = 0; it < nit; ++it) SPLIT_NT_TILE(0, it)
   }
 #undef SPLIT_NT_TILE
+#undef SPLIT_NT_TILE_DB
   SSTAMP(1);       // K loop
 #undef A_LOAD
 #undef KLIM
@@ -539,7 +588,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     // max |d_gates| of the step just produced: the next step's A scale.  One commit per WORKGROUP: the 4096 waves of a
     // step finish together, all would find the slot at its old value and each issue its (serialised, ~12 ns) atomic
     {
-      __shared__ float wmx[4 * KW];
+      float* wmx = reinterpret_cast<float*>(smem_all + C_BYTES);     // group 0's image, past its C tile: nobody reads it
       omax = wave_max(omax);
       if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = omax;
       __syncthreads();
@@ -603,7 +652,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     }
   }
   if (p.c_absmax0) {                                    // (block-uniform pointer; every lane left the loop together)
-    __shared__ float wmx0[4 * KW];                      // one commit per workgroup (see the BPTT epilogue)
+    float* wmx0 = reinterpret_cast<float*>(smem_all + C_BYTES);     // one commit per workgroup (see the BPTT epilogue)
     omax = wave_max(omax);
     if ((threadIdx.x & 63) == 0) wmx0[threadIdx.x >> 6] = omax;
     __syncthreads();
@@ -698,7 +747,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   constexpr int MODE = SPLIT_TN_MODE, NPL = npl(MODE);
   typedef typename Frag<MODE>::type frag8;
   constexpr int A_BYTES = NPL * BM * ROW_B, B_BYTES = NPL * BN * ROW_B;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[A_BYTES + B_BYTES > 8 * BN * 4 ? A_BYTES + B_BYTES : 8 * BN * 4];
+#ifndef SPLIT_TN_DBUF
+#define SPLIT_TN_DBUF 0     // 1: two LDS operand images, one barrier per K tile (as SPLIT_NT_DBUF)
+#endif
+  constexpr int OP_BYTES = A_BYTES + B_BYTES, NBUF = SPLIT_TN_DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * OP_BYTES > 8 * BN * 4 ? NBUF * OP_BYTES : 8 * BN * 4];
   float SA = 1.f, SB = 1.f, INV_A = 1.f, INV_B = 1.f;
   if (MODE == MODE_F16X2) {
     SA = pow2_scale(*p.a_absmax); SB = pow2_scale(*p.b_absmax);
@@ -764,6 +817,35 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   }
   __syncthreads();
 
+  if (SPLIT_TN_DBUF) {
+    for (int it = 0; it < nkt; ++it) {
+      frag8 af[TM][NPL], bf[TN][NPL];
+      const unsigned char* Ac = As + (it & 1) * OP_BYTES;
+      const unsigned char* Bc = Bs + (it & 1) * OP_BYTES;
+      unsigned char* An = As + ((it + 1) & 1) * OP_BYTES;
+      unsigned char* Bn = Bs + ((it + 1) & 1) * OP_BYTES;
+      read_frags<BM, BN, MODE, true>(Ac, Bc, wm, wn, li, kh, 0, af, bf);
+      const int kcur = (kt0 + min(it + 1, nkt - 1)) * BK, knext = (kt0 + min(it + 2, nkt - 1)) * BK;
+      tn_piece_store<BM, MODE>(An, ra, p.K - kcur, SA);
+      tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
+      tn_piece_store<BN, MODE>(Bn, rb, p.K - kcur, SB);
+      tn_colsum_acc(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);
+      tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
+      mma_frags<TM, TN>(af, bf, acc);
+      read_frags<BM, BN, MODE, true>(Ac, Bc, wm, wn, li, kh, 1, af, bf);
+      __syncthreads();                                 // tile it + 1 is visible; everybody has read tile it
+      mma_frags<TM, TN>(af, bf, acc);
+      if (SPLIT_TN_FLUSH > 0 && (it + 1) % SPLIT_TN_FLUSH == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+      }
+    }
+    __syncthreads();                                   // the colsum reduction below reuses the operand images
+  } else
   for (int it = 0; it < nkt; ++it) {
     frag8 af[TM][NPL], bf[TN][NPL];
     read_frags<BM, BN, MODE, true>(As, Bs, wm, wn, li, kh, 0, af, bf);

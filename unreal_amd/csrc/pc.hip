@@ -94,6 +94,9 @@ __device__ __forceinline__ void hp_store_planes(unsigned char* hpp, int gtid, co
     if (id < C2_POS * 8) {
       u32x2p pl[NPLP];
       split4p(r[c], scale, pl);
+      // hp = relu(...) >= 0: the backward kernel's ReLU mask reads "hi != 0" (common.h: keep_positive_visible)
+      pl[0][0] = keep_positive_visible(pl[0][0], r[c][0], r[c][1]);
+      pl[0][1] = keep_positive_visible(pl[0][1], r[c][2], r[c][3]);
 #pragma unroll
       for (int t = 0; t < NPLP; ++t) *reinterpret_cast<u32x2p*>(hpp + t * HPP_PLANE + (id >> 3) * HPP_ROW + (id & 7) * 8) = pl[t];
     }

@@ -21,9 +21,11 @@ class BatchedMazeEnvironment(object):
         self.reset()
 
     def view(self, b0, b1):
-        """The environments [b0, b1) as a batched environment of their own (shares the ring memory)."""
+        """The environments [b0, b1) as a batched environment of their own (shares the ring memory).  `base_actor` = b0:
+        frame indices the view's rollout_step prepares are indices into THIS environment's ring."""
         v = object.__new__(BatchedMazeEnvironment)
         v.B, v.ring = b1 - b0, ops.ring_view(self.ring, b0, b1)
+        v.base_actor = b0
         return v
 
     @staticmethod
@@ -37,10 +39,12 @@ class BatchedMazeEnvironment(object):
                 track_score=False):
         ops.maze_step(self.ring, actions, active, out_reward, out_terminal, reset_on_terminal, track_score)
 
-    def rollout_step(self, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end, **nxt):
-        """process() + the rollout loop's bookkeeping (+ the next step's frame indices / LSTM-input columns) fused."""
+    def rollout_step(self, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
+                     index_parent=False, **nxt):
+        """process() + the rollout loop's bookkeeping (+ the next step's frame indices / LSTM-input columns) fused.
+        `index_parent` (views only): the prepared frame indices address the ring this view was cut from."""
         ops.maze_rollout_step(self.ring, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
-                              **nxt)
+                              base_actor=getattr(self, "base_actor", 0) if index_parent else 0, **nxt)
 
     def stop(self):
         pass

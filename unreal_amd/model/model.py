@@ -308,8 +308,14 @@ class UnrealModel(object):
         self.slots.reset()
         self.pass_id += 1
 
+    def ws_slots(self, ws):
+        """The workspace's absmax slots of the current pass (max f2, max LSTM input x, max c1), taken on first use."""
+        if getattr(ws, "pass_id", None) != self.pass_id:
+            ws.s_f2, ws.s_x, ws.s_c1, ws.pass_id = self.new_slot(), self.new_slot(), self.new_slot(), self.pass_id
+        return ws.s_f2, ws.s_x, ws.s_c1
+
     def encode_rows(self, ring, ws, row0, nrows, lar_from_ring=True, save_c1=True, clip_lar=False,
-                    objective_slot_offset=0, actor_ring=None, lar_prefilled=False, lstm_x=True):
+                    objective_slot_offset=0, actor_ring=None, lar_prefilled=False, lstm_x=True, slots=None):
         """conv encoder -> fc (+ last_action_reward[_objective] columns and the input half of the LSTM gates) for
         rows [row0, row0+nrows) of a path workspace.  `objective_slot_offset` = -1 reproduces trainer.py:300, where the
         bootstrap value is fed the objective of the previous frame's state.  `lstm_x` False: a single time step follows
@@ -326,10 +332,11 @@ class UnrealModel(object):
         # the backward read all of them, so every block maxes into the same two slots (a block's own products then use the
         # running maximum: >= its rows', deterministic because the launches are stream-ordered).  Blocks encoded on
         # separate streams (host-fed half-batches, `actor_ring`) take fresh slots and merge them into the workspace's.
-        if getattr(ws, "pass_id", None) != self.pass_id:
-            ws.s_f2, ws.s_x, ws.s_c1, ws.pass_id = self.new_slot(), self.new_slot(), self.new_slot(), self.pass_id
-        own = actor_ring is not None
-        s_f2, s_fc = (self.new_slot(), self.new_slot()) if own else (ws.s_f2, ws.s_x)
+        # `slots` = (s_f2, s_x): a caller that runs row blocks of one workspace on several streams (Trainer's half-batch
+        # rollout) hands every stream its own running pair and merges them into the workspace's once, after the join.
+        self.ws_slots(ws)
+        own = actor_ring is not None and slots is None
+        s_f2, s_fc = slots if slots is not None else ((self.new_slot(), self.new_slot()) if own else (ws.s_f2, ws.s_x))
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
                         p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2,
                         c1_max=ws.s_c1 if c1 is not None else None)

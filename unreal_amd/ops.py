@@ -137,8 +137,9 @@ def maze_step(ring, actions, active=None, out_reward=None, out_terminal=None, re
 
 
 def maze_rollout_step(ring, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
-                      next_idx=None, next_lar=None, lar_ld=0, lar_col0=0, A=0):
-    """maze_step + rollout_advance (+ cur_idx and lar_fill for the NEXT step's rows) in one launch."""
+                      next_idx=None, next_lar=None, lar_ld=0, lar_col0=0, A=0, base_actor=0):
+    """maze_step + rollout_advance (+ cur_idx and lar_fill for the NEXT step's rows) in one launch.  `base_actor`: index
+    of this (view's) first actor in the ring the next_idx values are meant for (see Ring.cur_idx)."""
     B = ring.B
     _chk(actions, "i32", B, "actions"); _chk(out_reward, "f32", B, "out_reward"); _chk(out_terminal, "i32", B, "out_terminal")
     for t in (active, active_log_t, n_steps, terminal_end):
@@ -149,7 +150,7 @@ def maze_rollout_step(ring, actions, out_reward, out_terminal, active, active_lo
           ptr(ring.count), ptr(ring.frames), ptr(ring.r_reward), ptr(ring.r_action), ptr(ring.r_terminal),
           ptr(ring.r_last_action), ptr(ring.r_last_reward), ptr(ring.r_pc), ptr(out_reward), ptr(out_terminal),
           ptr(ring.episode_reward), ptr(ring.score_out), ptr(ring.score_valid), ptr(active), ptr(active_log_t),
-          ptr(n_steps), ptr(terminal_end), ptr(next_idx), ptr(next_lar), int(lar_ld), int(lar_col0), int(A))
+          ptr(n_steps), ptr(terminal_end), ptr(next_idx), ptr(next_lar), int(lar_ld), int(lar_col0), int(A), int(base_actor))
 
 
 def pixel_change_u8(frames, idx_new, idx_old, denom, out):

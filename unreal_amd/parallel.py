@@ -130,6 +130,29 @@ def shutdown():
         dist.destroy_process_group()
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT touching the HIP / HSA runtime (the self-launcher must stay a process
+    that never initialised the GPU): KFD topology nodes with SIMDs, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when set.  None if the topology is not readable (then the ranks find out themselves)."""
+    import glob
+    n = 0
+    try:
+        nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+        if not nodes:
+            return None
+        for f in nodes:
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 # ---- self-launcher ----------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -153,8 +176,14 @@ def launch_ranks(script, argv, world, extra_env=None, poll_s=0.5, grace_s=20.0):
     import signal
     procs = []
     interrupted = 0
+    state = {"reaping": False, "pending": 0}
 
     def _on_signal(signum, frame):
+        # while the children are being reaped (or one is being started) a second TERM / HUP -- an outer `timeout -k`
+        # sends TERM, then more -- must not abort that work: it is remembered, not raised
+        if state["reaping"]:
+            state["pending"] = signum
+            return
         raise _Terminated(signum)
 
     old = {}
@@ -190,7 +219,13 @@ def launch_ranks(script, argv, world, extra_env=None, poll_s=0.5, grace_s=20.0):
             if extra_env:
                 env.update(extra_env)
             out = None if r == 0 else sys.stderr
-            procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+            state["reaping"] = True                    # a signal between Popen() returning and append() would leak the child
+            try:
+                procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=out))
+            finally:
+                state["reaping"] = False
+            if state["pending"]:
+                raise _Terminated(state["pending"])
         first_fail = None
         while True:
             codes = [p.poll() for p in procs]
@@ -206,9 +241,16 @@ def launch_ranks(script, argv, world, extra_env=None, poll_s=0.5, grace_s=20.0):
     except _Terminated as e:
         interrupted = 128 + int(e.args[0])
     finally:
-        _reap()
+        state["reaping"] = True                        # from here on signals are recorded, never raised: _reap() completes
+        try:
+            _reap()
+        except KeyboardInterrupt:                      # Ctrl-C during the reap: finish it (children are killed by PID)
+            interrupted = interrupted or 130
+            _reap()
         for sig, h in old.items():
             signal.signal(sig, h)
+        if state["pending"] and not interrupted:
+            interrupted = 128 + int(state["pending"])
     if interrupted:
         return interrupted
     worst = 0

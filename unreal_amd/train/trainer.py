@@ -227,6 +227,7 @@ class Trainer(object):
             env = self.full_environment if self.groups == 1 else self.full_environment.view(b0, b1)
             self._group_views.append((env, self.full_lstm_c[b0 * 256:b1 * 256], self.full_lstm_h[b0 * 256:b1 * 256], b0))
         self._select_group(0)
+        self._rollout_split_setup()
 
     @property
     def aux_ws(self):
@@ -360,6 +361,68 @@ class Trainer(object):
             done.record(p["stream"])
             main.wait_event(done)
 
+    # Maze actors: the T rollout steps as `rollout_parts` half-batches on their own HIP streams.  A
+    # step is a chain of five dependent launches (conv encoder, fc, LSTM cell, policy + draw, environment) of which only
+    # the first fills the chip; with two halves in flight one half's latency-bound launches run beside the other half's
+    # encoder.  Same kernels, same rows, same draws as the lock-step loop.  0 / 1 = off.  Decided by same-process A/B
+    # (tools/exp/rollout_split_ab.py, profiles/r04_ab_summary.md).
+    rollout_parts_default = 0
+    ROLLOUT_SPLIT_MIN_ACTORS = 2048
+
+    def _rollout_split_setup(self):
+        """Per group: the halves' environment views, streams and running absmax slot pairs (built once)."""
+        n_parts = self.rollout_parts_default
+        self._split = None
+        if self.env_type != "maze" or n_parts < 2 or self.Bg % n_parts or self.Bg < self.ROLLOUT_SPLIT_MIN_ACTORS:
+            return
+        Bp = self.Bg // n_parts
+        streams = [torch.cuda.Stream(device=self.device) for _ in range(n_parts)]
+        self._split = []
+        for env, _, _, _ in self._group_views:
+            self._split.append([dict(b0=k * Bp, n=Bp, env=env.view(k * Bp, (k + 1) * Bp), stream=streams[k])
+                                for k in range(n_parts)])
+
+    def _rollout_steps_split(self):
+        B, T, A, ws, net = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network
+        parts = self._split[self.group]
+        main = torch.cuda.current_stream()
+        s_f2, s_x, _ = net.ws_slots(ws)
+        start = torch.cuda.Event()
+        start.record(main)
+        for p in parts:
+            p["slots"] = (net.new_slot(), net.new_slot())
+            p["stream"].wait_event(start)
+        for t in range(T):
+            for p in parts:
+                b0, n = p["b0"], p["n"]
+                r0 = t * B + b0
+                with torch.cuda.stream(p["stream"]):
+                    if t == 0:
+                        p["env"].ring.cur_idx(out=ws.frame_idx[r0:r0 + n], base_actor=b0)
+                    net.encode_rows(self.ring, ws, r0, n, lar_from_ring=False, save_c1=ws.c1 is not None,
+                                    actor_ring=p["env"].ring, lar_prefilled=t > 0 and self.use_lstm, lstm_x=False,
+                                    slots=p["slots"])
+                    if self.use_lstm:
+                        net.lstm_step(ws, t, B, b0, n, fused_x=True)
+                    feat, ld = net.features(ws, r0)
+                    net.policy_step(n, feat, ld, self.u_act[r0:r0 + n], self.pi[r0 * A:(r0 + n) * A], self.v[r0:r0 + n],
+                                    self.actions[r0:r0 + n])
+                    nxt = {}
+                    if t + 1 < T:
+                        nxt = dict(next_idx=ws.frame_idx[r0 + B:r0 + B + n])
+                        if self.use_lstm:
+                            nxt.update(next_lar=ws.xcat[(r0 + B) * ws.xld:], lar_ld=ws.xld, lar_col0=256, A=A)
+                    p["env"].rollout_step(self.actions[r0:r0 + n], self.rewards[r0:r0 + n], self.terminals[r0:r0 + n],
+                                          self.active[b0:b0 + n], self.active_log[r0:r0 + n], self.n_steps[b0:b0 + n],
+                                          self.terminal_end[b0:b0 + n], index_parent=True, **nxt)
+        for p in parts:                                          # join: the learner continues on the caller's stream
+            done = torch.cuda.Event()
+            done.record(p["stream"])
+            main.wait_event(done)
+        for p in parts:                                          # the halves' running maxima cover the workspace's rows
+            ops.absmax(1, 1, p["slots"][0], 1, s_f2)
+            ops.absmax(1, 1, p["slots"][1], 1, s_x)
+
     def _rollout(self):
         """[Base A3C] n_step_TD lock-step steps, bootstrap value, n-step returns (trainer.py:218-336)."""
         B, T, A, ws, net = self.Bg, self.n_step_TD, self.action_size, self.base_ws, self.local_network
@@ -372,8 +435,11 @@ class Trainer(object):
         self.draws.uniform(self.u_act)
         if self.overlap_host:
             self._rollout_steps_overlapped()
+        split = getattr(self, "_split", None) is not None
+        if split:
+            self._rollout_steps_split()
         fused = self.env_type == "maze"      # the maze step kernel also does the loop bookkeeping and prepares step t+1
-        for t in range(0 if not self.overlap_host else T, T):
+        for t in range(0 if not (self.overlap_host or split) else T, T):
             s = slice(t * B, (t + 1) * B)
             self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s],
                               prefilled=fused and t > 0)
