@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 export UNREAL_BENCH_SIDECAR="$OUT/bench_run.json"      # bench.py records what it ran (actors, groups, frames per launch)
 run() {   # name, counters...
   local name=$1; shift
+  export UNREAL_SAVE_MAPS="$OUT/$name.maps.txt"        # the process's DSO map: a crash under the profiler can then be symbolised
   timeout -k 10 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- \
       python3 "$ROOT/bench.py" --no-cpu-baseline "${ARGS[@]}" > "$OUT/$name.log" 2>&1
   local rc=$?

@@ -277,6 +277,7 @@ class Trainer(object):
         net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
 
     FILL_SYNC_EVERY = 64
+    GROUP_SYNC_EVERY = 16
 
     def _fill_experience(self, sess=None):
         """One policy step per call until every actor's replay is full (trainer.py:176-205)."""
@@ -695,6 +696,11 @@ class Trainer(object):
             ops.rollout_stats(self.Bg, self.n_steps, self.ring.score_valid, self.ring.score_out, self.stats)
             if G > 1:
                 ops.axpy(1.0 / G, self.losses, self.loss_sum)
+                # bound the un-synchronised dispatch queue like the replay fill does (a group pass is ~300 launches: at
+                # G = 64 one call would enqueue ~19 k dispatches before its only host sync; rocprofv3's counter thread
+                # did not survive ~24 k in the fill, profiles/r02_pmc_fault.log).  One sync per 16 groups: < 0.1 % of a call.
+                if (g + 1) % self.GROUP_SYNC_EVERY == 0 and g + 1 < G:
+                    torch.cuda.current_stream().synchronize()
         if G > 1:
             self._select_group(0)
         if not sync_stats:                               # stats keep accumulating on the device
