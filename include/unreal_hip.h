@@ -51,6 +51,17 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
                              float* next_lar /*nullable*/, int lar_ld, int lar_col0, int A,
                              int idx_base_actor /* next_idx[b] = (idx_base_actor + b) * H1 + slot: a half-batch whose
                                                    rows index the whole ring */, void* stream);
+/* unreal_policy_step + unreal_maze_rollout_step in ONE launch (trainer.py:236-296: run_base_policy_and_value, choose_action,
+ * environment.process of one rollout step): the workgroup that steps an actor first computes its pi / V from the feature row
+ * X[b] (K = 256) and draws its action from u[b] -- bit-identical to the two-launch path.  A must be 4 (the maze). */
+int unreal_maze_policy_rollout_step(int B, int H1, const float* X, int ldx, const float* Wp, const float* bp, const float* Wv,
+                                    const float* bv, const double* u, float* pi_out, float* v_out, int* actions_out, int* pos,
+                                    int* last_action, float* last_reward, int* count, uint8_t* frames, float* r_reward,
+                                    int* r_action, int* r_terminal, int* r_last_action, float* r_last_reward, float* r_pc,
+                                    float* out_reward, int* out_terminal, float* episode_reward, float* score_out,
+                                    int* score_valid, int* active, int* active_log_t, int* n_steps, int* terminal_end,
+                                    int* next_idx /*nullable*/, float* next_lar /*nullable*/, int lar_ld, int lar_col0, int A,
+                                    int idx_base_actor, void* stream);
 int unreal_maze_reset(int B, int H1, const int* mask, int* pos, int* last_action, float* last_reward,
                       const int* count, uint8_t* frames, void* stream);
 /* host-fed environments (environment/lab_environment.py:78-119 contract): `staged` holds one uint8

@@ -827,3 +827,51 @@ def test_policy_step_is_the_three_kernel_path(A):
         ops.policy_step(rows, A, X, ld, Wp, bp, Wv, bv, uu, pi1, v1, a1)
         assert torch.equal(pi0, pi1) and torch.equal(v0, v1) and torch.equal(a0, a1)
     assert len(torch.unique(a1)) > 1
+
+
+@pytest.mark.parametrize("B", [4096, 1500, 512, 3])       # 8 actors per workgroup / ragged / 2 per workgroup / tiny
+def test_fused_policy_maze_rollout_step_is_the_two_launch_path(ops, B):
+    """unreal_maze_policy_rollout_step == unreal_policy_step + unreal_maze_rollout_step, bit for bit: pi, V, actions,
+    rewards / terminals, the loop bookkeeping, the next step's frame indices and last_action_reward columns, and the
+    ring itself (frames, metadata, pixel change) over several chained steps with actors finishing on the way."""
+    H, A, xld = 6, 4, 264
+    rs = np.random.RandomState(B)
+    Wp = dev(rs.uniform(-.3, .3, 256 * A), torch.float32); bp = dev(rs.uniform(-.1, .1, A), torch.float32)
+    Wv = dev(rs.uniform(-.3, .3, 256), torch.float32); bv = dev(rs.uniform(-.1, .1, 1), torch.float32)
+    rings = [ops.Ring(B, H, DEV), ops.Ring(B, H, DEV)]
+    st = []
+    for ring in rings:
+        ops.maze_reset(ring)
+        pos = ring.pos.cpu()
+        pos[0::2] = 5; pos[1::2] = 0                   # one RIGHT from the goal: episodes end inside the test
+        pos[0:2 * (B // 2):2] = 0; pos[1:2 * (B // 2):2] = 2
+        ring.pos.copy_(pos)
+        z = lambda n, dt=torch.int32: torch.zeros(n, dtype=dt, device=DEV)
+        st.append(dict(active=torch.ones(B, dtype=torch.int32, device=DEV), log=z(B), n=z(B), te=z(B), r=z(B, torch.float32),
+                       t=z(B), a=z(B), pi=z(B * A, torch.float32), v=z(B, torch.float32), idx=z(B),
+                       lar=torch.zeros(B * xld, device=DEV)))
+    for step in range(5):
+        X = dev(rs.uniform(-1, 1, (B, 256)), torch.float32).view(-1)
+        u = dev(rs.uniform(0, 1, B), torch.float64)
+        s0, s1 = st
+        ops.policy_step(B, A, X, 256, Wp, bp, Wv, bv, u, s0["pi"], s0["v"], s0["a"])
+        ops.maze_rollout_step(rings[0], s0["a"], s0["r"], s0["t"], s0["active"], s0["log"], s0["n"], s0["te"],
+                              next_idx=s0["idx"], next_lar=s0["lar"], lar_ld=xld, lar_col0=256, A=A)
+        ops.maze_policy_rollout_step(rings[1], X, 256, Wp, bp, Wv, bv, u, s1["pi"], s1["v"], s1["a"], s1["r"], s1["t"],
+                                     s1["active"], s1["log"], s1["n"], s1["te"], next_idx=s1["idx"], next_lar=s1["lar"],
+                                     lar_ld=xld, lar_col0=256, A=A)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), (step, k)
+        for name in ("frames", "r_reward", "r_action", "r_terminal", "r_last_action", "r_last_reward", "pos", "count",
+                     "last_action", "last_reward", "episode_reward", "score_out", "score_valid"):
+            assert torch.equal(getattr(rings[0], name), getattr(rings[1], name)), (step, name)
+        n_live = (rings[0].count.cpu().numpy() > 0).sum()
+        cnt = rings[0].count.cpu().numpy().astype(np.int64)
+        H1 = H + 1
+        # pixel change of the slots written so far (the rest of r_pc is uninitialised memory)
+        for b in (0, B // 2, B - 1):
+            for c in range(min(int(cnt[b]), H)):
+                a_ = rings[0].r_pc[(b * H1 + c) * 400:(b * H1 + c + 1) * 400]
+                b_ = rings[1].r_pc[(b * H1 + c) * 400:(b * H1 + c + 1) * 400]
+                assert torch.equal(a_, b_)
+    assert int(st[0]["te"].sum()) > 0 and int(st[0]["active"].sum()) < B       # some actors did finish

@@ -19,9 +19,10 @@ pytestmark = pytest.mark.gpu
 # losses 0.06, gradients 0.04 (profiles/r04_parity_margins.md).
 LOSS_ATOL, LOSS_RTOL = 1e-6, 1e-4
 GRAD_ATOL, GRAD_REL = 1e-6, 2e-5
-# host-fed actors (uint8 observations / 255, raw rewards): the bars of rounds 1-3, margins recorded since round 4
-HF_LOSS_ATOL, HF_LOSS_RTOL = 3e-4, 3e-4
-HF_GRAD_ATOL, HF_GRAD_REL = 1e-5, 3e-4
+# host-fed actors (uint8 observations / 255, raw rewards): the same bars (rounds 1-3: 3e-4 / 3e-4; measured on MI355X
+# with those: losses <= 0.004 of rel 1e-4, gradients <= 0.007 of 3e-4 of max |g|)
+HF_LOSS_ATOL, HF_LOSS_RTOL = LOSS_ATOL, LOSS_RTOL
+HF_GRAD_ATOL, HF_GRAD_REL = GRAD_ATOL, GRAD_REL
 
 from oracle import maze as OM
 from oracle.trainer import OracleTrainer, ExplicitDraws

@@ -13,6 +13,7 @@
 // sample-able.  One workgroup (256 threads) per actor: 21,168 B of frame are written with
 // 16 B/lane coalesced stores; the kernel is a pure HBM-write stream.
 #include "common.h"
+#include "policy_row.h"
 
 namespace {
 
@@ -129,6 +130,12 @@ struct StepArgs {
   float* next_lar;       // nullable: [B][lar_ld] rows of the next step's LSTM input: one-hot last action | last reward
   int lar_ld, lar_col0, A;
   int idx_base;          // index of this launch's first actor in the ring next_idx is meant for (a half-batch of a ring)
+  // fused policy step (unreal_maze_policy_rollout_step; pol_x null: the actions are given): the actors' feature rows ->
+  // pi, V and the drawn action, computed by the workgroup that then steps those actors (one launch less per rollout step)
+  const float* pol_x; int pol_ldx;
+  const float* Wp; const float* bp; const float* Wv; const float* bv;
+  const double* pol_u;
+  float* pi_out; float* v_out; int* act_out;
 };
 
 // APG actors per workgroup: 8 when the batch fills the chip (the wall image is built once per workgroup: ~2.5 us of VALU),
@@ -143,13 +150,23 @@ __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   __shared__ int s_flag[APG], s_x[APG], s_y[APG], s_a[APG],
       s_cnt[APG], s_la[APG], s_prev[APG], s_ns[APG];
   __shared__ float s_lr[APG], s_ep[APG];
+  if (p.pol_x) {       // (workgroup-uniform) policy of this workgroup's actors: wave w takes actors w, w + 4, ...
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wave; k < APG; k += 4) {
+      const int b = blockIdx.x * APG + k;
+      if (b >= p.B) break;
+      const int act = policy_row<4>(p.pol_x + (size_t)b * p.pol_ldx, p.Wp, p.bp, p.Wv, p.bv, p.pol_u + b,
+                                    p.pi_out + (size_t)b * 4, p.v_out + b, lane);
+      if (lane == 0) { s_a[k] = act; p.act_out[b] = act; }
+    }
+  }
   if (threadIdx.x < APG) {
     const int k = threadIdx.x, b = blockIdx.x * APG + k;
     if (b < p.B) {
       const int cnt = p.count[b];
       s_flag[k] = p.active_rw ? p.active_rw[b] : (p.active ? p.active[b] : 1);
       s_x[k] = p.pos[2 * b]; s_y[k] = p.pos[2 * b + 1];
-      s_a[k] = p.actions[b];
+      if (!p.pol_x) s_a[k] = p.actions[b];
       s_cnt[k] = cnt;
       s_la[k] = p.last_action[b];
       s_lr[k] = p.last_reward[b];
@@ -483,7 +500,7 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
   StepArgs p{B, H1, actions, active, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
-             nullptr, 0, 0, 0, 0};
+             nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
@@ -503,7 +520,31 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
   StepArgs p{B, H1, actions, nullptr, pos, last_action, last_reward, count, frames, r_reward, r_action,
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
-             lar_col0, A, idx_base_actor};
+             lar_col0, A, idx_base_actor, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  return unreal_launch_status();
+}
+
+int unreal_maze_policy_rollout_step(int B, int H1, const float* X, int ldx, const float* Wp, const float* bp, const float* Wv,
+                                    const float* bv, const double* u, float* pi_out, float* v_out, int* actions_out, int* pos,
+                                    int* last_action, float* last_reward, int* count, uint8_t* frames, float* r_reward,
+                                    int* r_action, int* r_terminal, int* r_last_action, float* r_last_reward, float* r_pc,
+                                    float* out_reward, int* out_terminal, float* episode_reward, float* score_out,
+                                    int* score_valid, int* active, int* active_log_t, int* n_steps, int* terminal_end,
+                                    int* next_idx, float* next_lar, int lar_ld, int lar_col0, int A, int idx_base_actor,
+                                    void* stream) {
+  if (B <= 0 || H1 < 2 || !pos || !count || !frames || !last_action || !last_reward) return UNREAL_EINVAL;
+  if (!X || ldx < LSTM_N || !Wp || !bp || !Wv || !bv || !u || !pi_out || !v_out || !actions_out) return UNREAL_EINVAL;
+  if (A != 4) return UNREAL_EINVAL;                  // the maze has four actions (maze_environment.py:98-112)
+  if (!episode_reward || !score_out || !score_valid || !active || !active_log_t || !n_steps || !terminal_end)
+    return UNREAL_EINVAL;
+  if (next_lar && (lar_col0 < 0 || lar_ld < lar_col0 + A + 1)) return UNREAL_EINVAL;
+  if (idx_base_actor < 0) return UNREAL_EINVAL;
+  StepArgs p{B, H1, nullptr, nullptr, pos, last_action, last_reward, count, frames, r_reward, r_action,
+             r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
+             score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
+             lar_col0, A, idx_base_actor, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, actions_out};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();

@@ -7,6 +7,7 @@
 //   policy / value heads 358-377, softmax 364; base loss 490-516; vr loss 559-566; rp 473-488, 569-576
 //   action choice: /root/reference/train/trainer.py:147-148 (numpy RandomState.choice = inverse CDF in fp64)
 #include "common.h"
+#include "policy_row.h"
 
 namespace {
 
@@ -205,51 +206,9 @@ __global__ __launch_bounds__(256) void policy_step_kernel(int rows, const float*
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  float acc[A], accv = 0.f;
-#pragma unroll
-  for (int n = 0; n < A; ++n) acc[n] = 0.f;
-  const float* x = X + (size_t)row * ldx;
-  for (int k = lane; k < LSTM_N; k += 64) {
-    float xv = x[k];
-#pragma unroll
-    for (int n = 0; n < A; ++n) acc[n] += xv * Wp[(size_t)k * A + n];
-    accv += xv * Wv[k];
-  }
-#pragma unroll
-  for (int n = 0; n < A; ++n) acc[n] = wave_sum(acc[n]);
-  accv = wave_sum(accv);
-  if (lane != 0) return;
-  v_out[row] = accv + bv[0];
-  float p[A];
-#pragma unroll
-  for (int n = 0; n < A; ++n) p[n] = acc[n] + bp[n];
-  float m = p[0];
-#pragma unroll
-  for (int a = 1; a < A; ++a) m = fmaxf(m, p[a]);
-  float s = 0.f;
-#pragma unroll
-  for (int a = 0; a < A; ++a) { float e = expf(p[a] - m); p[a] = e; s += e; }
-#pragma unroll
-  for (int a = 0; a < A; ++a) { p[a] = p[a] / s; pi_out[(size_t)row * A + a] = p[a]; }
-  if (u) {
-    double tot = 0.0;
-#pragma unroll
-    for (int a = 0; a < A; ++a) tot += (double)p[a];
-    double run = 0.0, uu = u[row];
-    int act = 0;
-#pragma unroll
-    for (int a = 0; a < A; ++a) {
-      run += (double)p[a];
-      if (run / tot <= uu) act = a + 1;     // searchsorted(cdf, u, side='right')
-    }
-    action[row] = min(act, A - 1);
-  } else {                                  // greedy (np.argmax: first maximum), for evaluation
-    int best = 0;
-#pragma unroll
-    for (int a = 1; a < A; ++a)
-      if (p[a] > p[best]) best = a;
-    action[row] = best;
-  }
+  const int act = policy_row<A>(X + (size_t)row * ldx, Wp, bp, Wv, bv, u ? u + row : nullptr, pi_out + (size_t)row * A,
+                                v_out + row, lane);
+  if (lane == 0) action[row] = act;
 }
 
 // A3C loss + gradient wrt logits and value.  losses[0..2] += (policy_loss, value_loss, entropy) * loss_scale

@@ -46,6 +46,15 @@ class BatchedMazeEnvironment(object):
         ops.maze_rollout_step(self.ring, actions, out_reward, out_terminal, active, active_log_t, n_steps, terminal_end,
                               base_actor=getattr(self, "base_actor", 0) if index_parent else 0, **nxt)
 
+    def policy_rollout_step(self, net, feat, ld, u, pi_out, v_out, actions, out_reward, out_terminal, active, active_log_t,
+                            n_steps, terminal_end, index_parent=False, **nxt):
+        """The policy head + action draw of `net` on the feature rows `feat` and rollout_step() in one launch."""
+        p = net.p
+        ops.maze_policy_rollout_step(self.ring, feat, ld, p["W_base_fc_p"], p["b_base_fc_p"], p["W_base_fc_v"],
+                                     p["b_base_fc_v"], u, pi_out, v_out, actions, out_reward, out_terminal, active,
+                                     active_log_t, n_steps, terminal_end,
+                                     base_actor=getattr(self, "base_actor", 0) if index_parent else 0, **nxt)
+
     def stop(self):
         pass
 

@@ -153,6 +153,29 @@ def maze_rollout_step(ring, actions, out_reward, out_terminal, active, active_lo
           ptr(n_steps), ptr(terminal_end), ptr(next_idx), ptr(next_lar), int(lar_ld), int(lar_col0), int(A), int(base_actor))
 
 
+def maze_policy_rollout_step(ring, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, actions, out_reward, out_terminal, active,
+                             active_log_t, n_steps, terminal_end, next_idx=None, next_lar=None, lar_ld=0, lar_col0=0, A=4,
+                             base_actor=0):
+    """policy_step + maze_rollout_step in one launch: the workgroup that steps an actor computes its pi / V / action first
+    (bit-identical to the two launches)."""
+    B = ring.B
+    if A != 4:
+        raise ValueError("the maze has 4 actions")
+    _chk(X, "f32", (B - 1) * ldx + 256, "X"); _chk(Wp, "f32", 256 * A); _chk(bp, "f32", A); _chk(Wv, "f32", 256)
+    _chk(bv, "f32", 1); _chk(u, "f64", B, "u"); _chk(pi_out, "f32", B * A); _chk(v_out, "f32", B)
+    _chk(actions, "i32", B, "actions"); _chk(out_reward, "f32", B, "out_reward"); _chk(out_terminal, "i32", B, "out_terminal")
+    for t in (active, active_log_t, n_steps, terminal_end):
+        _chk(t, "i32", B)
+    _chk(next_idx, "i32", B, "next_idx", optional=True)
+    _chk(next_lar, "f32", (B - 1) * lar_ld + lar_col0 + A + 1 if next_lar is not None else None, "next_lar", optional=True)
+    _call("unreal_maze_policy_rollout_step", B, ring.H1, ptr(X), int(ldx), ptr(Wp), ptr(bp), ptr(Wv), ptr(bv), ptr(u),
+          ptr(pi_out), ptr(v_out), ptr(actions), ptr(ring.pos), ptr(ring.last_action), ptr(ring.last_reward), ptr(ring.count),
+          ptr(ring.frames), ptr(ring.r_reward), ptr(ring.r_action), ptr(ring.r_terminal), ptr(ring.r_last_action),
+          ptr(ring.r_last_reward), ptr(ring.r_pc), ptr(out_reward), ptr(out_terminal), ptr(ring.episode_reward),
+          ptr(ring.score_out), ptr(ring.score_valid), ptr(active), ptr(active_log_t), ptr(n_steps), ptr(terminal_end),
+          ptr(next_idx), ptr(next_lar), int(lar_ld), int(lar_col0), int(A), int(base_actor))
+
+
 def pixel_change_u8(frames, idx_new, idx_old, denom, out):
     N = idx_new.numel()
     _chk(frames, "u8"); _chk(idx_new, "i32", N); _chk(idx_old, "i32", N); _chk(out, "f32", N * PC_CELLS)

@@ -263,9 +263,10 @@ class Trainer(object):
         raise NotImplementedError("actions are drawn on the device; see ops.softmax_sample")
 
     # ---------------------------------------------------------------------------------------------------
-    def _policy_step(self, ws, t, u, actions_out, pi_out, v_out, prefilled=False):
+    def _policy_step(self, ws, t, u, actions_out, pi_out, v_out, prefilled=False, heads=True):
         """Forward the current observations of all actors as time row-block t of `ws` and draw actions.  `prefilled`:
-        the previous environment step has already written this block's frame indices and last_action_reward columns."""
+        the previous environment step has already written this block's frame indices and last_action_reward columns.
+        `heads` False: the caller's environment step computes pi / V / action itself (fused launch); -> (feat, ld)."""
         B, A, net = self.Bg, self.action_size, self.local_network
         if not prefilled:
             self.ring.cur_idx(out=ws.frame_idx[t * B:(t + 1) * B])
@@ -274,7 +275,9 @@ class Trainer(object):
         if self.use_lstm:
             net.lstm_step(ws, t, B, fused_x=True)
         feat, ld = net.features(ws, t * B)
-        net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
+        if heads:
+            net.policy_step(B, feat, ld, u, pi_out, v_out, actions_out)
+        return feat, ld
 
     FILL_SYNC_EVERY = 64
     GROUP_SYNC_EVERY = 16
@@ -369,6 +372,9 @@ class Trainer(object):
     # (tools/exp/rollout_split_ab.py, profiles/r04_ab_summary.md).
     rollout_parts_default = 0
     ROLLOUT_SPLIT_MIN_ACTORS = 2048
+    # Maze rollout: policy head + softmax + action draw inside the environment step's launch (unreal_maze_policy_rollout_step,
+    # bit-identical to unreal_policy_step + unreal_maze_rollout_step; one ~5-7 us launch less per step)
+    fuse_policy_env = True
 
     def _rollout_split_setup(self):
         """Per group: the halves' environment views, streams and running absmax slot pairs (built once)."""
@@ -440,16 +446,23 @@ class Trainer(object):
         if split:
             self._rollout_steps_split()
         fused = self.env_type == "maze"      # the maze step kernel also does the loop bookkeeping and prepares step t+1
+        fuse_policy = fused and self.fuse_policy_env     # policy head + draw inside the environment step's launch
         for t in range(0 if not (self.overlap_host or split) else T, T):
             s = slice(t * B, (t + 1) * B)
-            self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A], self.v[s],
-                              prefilled=fused and t > 0)
+            feat, ld = self._policy_step(ws, t, self.u_act[s], self.actions[s], self.pi[t * B * A:(t + 1) * B * A],
+                                         self.v[s], prefilled=fused and t > 0, heads=not fuse_policy)
             if fused:
                 nxt = {}
                 if t + 1 < T:
                     nxt = dict(next_idx=ws.frame_idx[(t + 1) * B:(t + 2) * B])
                     if self.use_lstm:
                         nxt.update(next_lar=ws.xcat[(t + 1) * B * ws.xld:], lar_ld=ws.xld, lar_col0=256, A=A)
+                if fuse_policy:
+                    self.environment.policy_rollout_step(net, feat, ld, self.u_act[s], self.pi[t * B * A:(t + 1) * B * A],
+                                                         self.v[s], self.actions[s], self.rewards[s], self.terminals[s],
+                                                         self.active, self.active_log[s], self.n_steps, self.terminal_end,
+                                                         **nxt)
+                    continue
                 self.environment.rollout_step(self.actions[s], self.rewards[s], self.terminals[s], self.active,
                                               self.active_log[s], self.n_steps, self.terminal_end, **nxt)
                 continue
