@@ -841,6 +841,7 @@ def test_fused_policy_maze_rollout_step_is_the_two_launch_path(ops, B):
     rings = [ops.Ring(B, H, DEV), ops.Ring(B, H, DEV)]
     st = []
     for ring in rings:
+        ring.frames.zero_(); ring.r_pc.zero_()         # (torch.empty: slots no step writes would hold stale allocator bytes)
         ops.maze_reset(ring)
         pos = ring.pos.cpu()
         pos[0::2] = 5; pos[1::2] = 0                   # one RIGHT from the goal: episodes end inside the test
