@@ -8,6 +8,7 @@ set -o pipefail
 TAG=$1; BUDGET=$2; shift 2
 SEEDS=${SEEDS:-"0 1 2"}
 mkdir -p gpurun_out/return
+STAMP=$(date +%m%d_%H%M%S)        # one evaluation file per call: gpurun merges a call's gpurun_out/ OVER the local one
 rc=0
 for cfg in "$@"; do
   IFS=: read -r B G STEPS CKPTS <<< "$cfg"
@@ -28,7 +29,7 @@ for cfg in "$@"; do
   done
   for p in "${pids[@]}"; do wait "$p" || rc=$?; done
   tail -q -n 1 gpurun_out/return/${TAG}_b${B}_g${G}_s*/stdout.log
-  python3 tools/return_eval.py --cap "${CAP:-2000}" "${dirs[@]}" >> gpurun_out/return/eval_${TAG}.jsonl 2>> gpurun_out/return/eval_${TAG}.err || { rc=$?; tail -n 5 gpurun_out/return/eval_${TAG}.err; }
+  python3 tools/return_eval.py --cap "${CAP:-2000}" "${dirs[@]}" >> gpurun_out/return/eval_${TAG}_${STAMP}.jsonl 2>> gpurun_out/return/eval_${TAG}_${STAMP}.err || { rc=$?; tail -n 5 gpurun_out/return/eval_${TAG}_${STAMP}.err; }
   rm -f gpurun_out/return/${TAG}_b${B}_g${G}_s*/ckpt-*.npz
   echo "[frontier] $cfg done rc=$rc at $(date +%T)"
 done

@@ -67,6 +67,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SPLIT_NT_DBUF
 #define SPLIT_NT_DBUF 0     // 1: two LDS operand images, one barrier per K tile (tools/exp/gemm_ab.py)
 #endif
+#ifndef SPLIT_NT_OCC3
+#define SPLIT_NT_OCC3 1     // three 128 x 128 workgroups per CU (168 VGPRs, epilogue staged in two 64-row halves so that a
+                            // workgroup needs 40,960 B of LDS instead of 67,648).  Round 4, tools/exp/gemm_ab.py: the K = 256
+                            // products (13,440 tiles of 8 K steps: prologue / epilogue-bound) 0.89-0.90x the time, the long-K
+                            // products unchanged, outputs bit-identical (profiles/r04_gemm_occ3_ab.log).  0: two per CU.
+#endif
 #ifndef SPLIT_ROW_DEAL
 #define SPLIT_ROW_DEAL 1    // 0: tile rows in lane order (tools/exp/ab_split_rows.py times both)
 #endif
@@ -288,7 +294,7 @@ __device__ __forceinline__ ASrc<DUAL> a_src(const SplitArgs& p, int kg) {
 }
 
 template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false>
-__global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kernel(SplitArgs p) {
+__global__ __launch_bounds__(256 * KW, KW == 1 ? ((SPLIT_NT_OCC3 && BM == 128 && EPI == 0) ? 3 : 2) : 1) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int MODE = SPLIT_NT_MODE, NPL = npl(MODE);
   typedef typename Frag<MODE>::type frag8;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
     INV_A = pow2_inv(SA);
     INV_W = pow2_inv(pow2_scale(*p.w_absmax));
   }
-  constexpr int C_BYTES = BM * (BN + 4) * 4;
+  constexpr bool HALF = SPLIT_NT_OCC3 && BM == 128 && EPI == 0 && KW == 1;      // epilogue staged in two 64-row halves
+  constexpr int C_BYTES = (HALF ? BM / 2 : BM) * (BN + 4) * 4;
   // DBUF: two operand images -- tile it + 1 is split / stored into the other one while tile it is multiplied, so a K tile
   // costs ONE workgroup barrier (stores visible) instead of two (all reads done; stores visible).  128 x 128: 2 x 40,960 B
   // per workgroup, two workgroups per CU use the 160 KB exactly.
@@ -484,6 +491,78 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? 2 : 1) void gemm_split_nt_kerne
   // tile in its own LDS image and the partials are summed group 0 first
   constexpr int CLD = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
+  if (HALF) {
+    // (EPI == 0, one wave group) the 128 x 128 tile leaves in two 64-row halves through a 33,792-byte staging area
+    const uint16_t* mbits = reinterpret_cast<const uint16_t*>(p.mask);
+    const bool vecC = ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
+                      (!p.bias || ((((uintptr_t)p.bias) & 15) == 0)) &&
+                      (!(p.flags & FLAG_RELU_MASK) || (((p.ldm & 3) == 0) && ((((uintptr_t)p.mask) & 15) == 0)));
+    constexpr int CV = BN / 4;
+    float omax = 0.f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      if (half) __syncthreads();                        // every lane has stored its pieces of the first half
+      if (wm == half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * CLD + wn * (BN / 2) + j * 32 + li] =
+                  MODE == MODE_F16X2 ? (acc[i][j][r] * INV_A) * INV_W : acc[i][j][r];
+      }
+      __syncthreads();
+      for (int id = threadIdx.x; id < (BM / 2) * CV; id += 256) {
+        const int r = id / CV, c4 = (id % CV) * 4;
+        const int row = m0 + half * (BM / 2) + r, col = n0 + c4;
+        if (row >= p.M || col >= p.N) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CLD + c4);
+        float* cp = p.C + (size_t)row * p.ldc + col;
+        if (vecC && col + 3 < p.N) {
+          if (p.bias) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col); v += b4; }
+          if (p.flags & FLAG_ACCUM) v += *reinterpret_cast<const f32x4*>(cp);
+          if (p.flags & FLAG_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.flags & FLAG_RELU_MASK) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(p.mask + (size_t)row * p.ldm + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = m4[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.flags & FLAG_RELU_BITS) {
+            const unsigned w = mbits[(size_t)row * p.ldm + (col >> 4)] >> (col & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((w >> e) & 1u) ? v[e] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(cp) = v;
+          omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (col + e >= p.N) break;
+            float x = v[e] + (p.bias ? p.bias[col + e] : 0.f);
+            if (p.flags & FLAG_ACCUM) x += cp[e];
+            if (p.flags & FLAG_RELU) x = fmaxf(x, 0.f);
+            if (p.flags & FLAG_RELU_MASK) x = (p.mask[(size_t)row * p.ldm + col + e] > 0.f) ? x : 0.f;
+            if (p.flags & FLAG_RELU_BITS) x = ((mbits[(size_t)row * p.ldm + ((col + e) >> 4)] >> ((col + e) & 15)) & 1u) ? x : 0.f;
+            cp[e] = x;
+            omax = fmaxf(omax, fabsf(x));
+          }
+        }
+      }
+    }
+    if (p.c_absmax0) {
+      __syncthreads();                                  // the staging area is free again
+      float* wmx0 = reinterpret_cast<float*>(smem_all);
+      omax = wave_max(omax);
+      if ((threadIdx.x & 63) == 0) wmx0[threadIdx.x >> 6] = omax;
+      __syncthreads();
+      if (threadIdx.x < 64) absmax_commit(p.c_absmax0, fmaxf(fmaxf(wmx0[0], wmx0[1]), fmaxf(wmx0[2], wmx0[3])));
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
