@@ -79,10 +79,12 @@ def _check_rows_vs_fp32(what, err, err32, e, axis):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(992, 256, 2592), (992, 2592, 256), (4096, 256, 1024), (62, 1024, 261)])
+@pytest.mark.parametrize("M,N,K", [(992, 256, 2592), (992, 2592, 256), (4096, 256, 1024), (62, 1024, 261),
+                                   (4030, 2592, 256), (24800, 256, 1024)])      # >= 384 tiles of 128 x 128: the big-tile kernels
 @pytest.mark.parametrize("which", ["rows", "kcols", "wrows", "rows+kcols"])
 def test_split_nt_dynamic_range(M, N, K, which):
-    """unreal_gemm_f32_split_nt (fc forward / fc dgrad / LSTM dgrad shapes + a ragged one)."""
+    """unreal_gemm_f32_split_nt (fc forward / fc dgrad / LSTM dgrad shapes + a ragged one; the last two shapes run the
+    128 x 128-tile kernel -- three workgroups per CU, epilogue staged in halves -- the others the 64 x 64 wave-group forms)."""
     from unreal_amd import ops
     rs = np.random.RandomState(M + N + K + len(which))
     A = rs.standard_normal((M, K))
@@ -377,7 +379,7 @@ def test_absmax_slot_is_committed_by_every_producer_variant():
     consumer's scale into 1 silently); the split-K form refuses one."""
     from unreal_amd import ops
     rs = np.random.RandomState(0)
-    for (M, N, K) in [(4096, 256, 512), (130, 2592, 256), (70, 256, 96), (512, 256, 2592), (1500, 1024, 200)]:   # 128^2, 64^2 KW 1/2/4
+    for (M, N, K) in [(4096, 2592, 256), (4096, 256, 512), (130, 2592, 256), (70, 256, 96), (512, 256, 2592), (1500, 1024, 200)]:   # 128^2, 64^2 KW 1/2/4
         A = dev32(rs.standard_normal((M, K))); W = dev32(rs.standard_normal((N, K)) * 0.05)
         sh = ops.SplitWeights(W, N, K, K, transpose=False)
         C = torch.zeros(M, N, device=DEV); slot = torch.zeros(1, device=DEV)

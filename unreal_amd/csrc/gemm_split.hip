@@ -294,7 +294,7 @@ __device__ __forceinline__ ASrc<DUAL> a_src(const SplitArgs& p, int kg) {
 }
 
 template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false>
-__global__ __launch_bounds__(256 * KW, KW == 1 ? ((SPLIT_NT_OCC3 && BM == 128 && EPI == 0) ? 3 : 2) : 1) void gemm_split_nt_kernel(SplitArgs p) {
+__global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : (SPLIT_NT_OCC3 && BM == 128 && EPI == 0) ? 3 : 2) : 1) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int MODE = SPLIT_NT_MODE, NPL = npl(MODE);
   typedef typename Frag<MODE>::type frag8;
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -1121,7 +1121,14 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
     a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
   }
   const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
-  if (blocks128 >= 384) {
+#ifndef SPLIT_NT_K256
+#define SPLIT_NT_K256 0     // 1: 64 x 128 tiles, four workgroups per CU, for the short-K products (tools/exp/gemm_ab.py)
+#endif
+  if (SPLIT_NT_K256 && blocks128 >= 384 && a.ktiles_per_split <= 8 && a.vecA) {
+    a.nbx = (N + 127) / 128; a.nby = (M + 63) / 64;
+    const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
+    hipLaunchKernelGGL((gemm_split_nt_kernel<64, 128, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (blocks128 >= 384) {
     a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
 #ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (tools/exp/gemm_ab.py)
