@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0
 # (power-limited).  Reported beside the nominal peaks as roofline.peak_sustained; `frac` stays against the nominal ones.
 HBM_SUSTAINED_GBS = 6200.0
 MFMA_SUSTAINED_CLOCK_FRACTION = 1.85 / 2.4
-PMC_FILE = "r03_pmc_bench.json"                                  # in-situ rocprofv3 --pmc passes of THIS program
+PMC_FILE = "r04_pmc_bench.json"                                  # in-situ rocprofv3 --pmc passes of THIS program
 
 
 def build_trainer(args, rank, world, device):
@@ -251,7 +251,7 @@ def main():
     avg_ms = kt["ms"] / max(kt["launches"], 1)
     achieved = (2.0 * mac * frames_per_launch) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     # HBM traffic per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r03_pmc_bench.json,
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS program (tools/pmc_bench.sh -> profiles/r04_pmc_bench.json,
     # corrected as MI355X_MICROARCH.md prescribes: FETCH doubled), mean over the launches of its timed calls.
     # The PMC file records the launch it measured (frames per launch, actors, groups); the figure is scaled to THIS run's
     # frames per launch when the schedule is the profiled one (same groups: same mix of launches) and null otherwise.

@@ -166,12 +166,12 @@ __device__ __forceinline__ void split4_terms(float x0, float x1, float x2, float
 }
 
 // split 4 consecutive-k fp32 values into three bf16 planes and store 8 bytes per plane; klim = K - k0 of that tile
-template <int ROWS, int MODE>
+template <int ROWS, int MODE, bool RAGGED = true>
 __device__ __forceinline__ void a_piece_store(unsigned char* S, f32x4 v, int klim, int p, int tid, float scale) {
   const int id = tid + 256 * p;
   const int r = row_deal(id / (BK / 4)), k = (id % (BK / 4)) * 4;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (k + e < klim) ? (MODE == MODE_F16X2 ? v[e] * scale : v[e]) : 0.f;
+  for (int e = 0; e < 4; ++e) v[e] = (!RAGGED || k + e < klim) ? (MODE == MODE_F16X2 ? v[e] * scale : v[e]) : 0.f;
   u32x2 pl[3];
   split4_terms<false, MODE>(v[0], v[1], v[2], v[3], pl);
 #pragma unroll
@@ -293,7 +293,9 @@ __device__ __forceinline__ ASrc<DUAL> a_src(const SplitArgs& p, int kg) {
   return s;
 }
 
-template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false>
+// RAG false (K a multiple of 32, one wave group, one A source: the big products of the trainer): no k of a tile lies past
+// K, the per-element selects of the A split go
+template <int BM, int BN, bool VEC, bool DEEP = (BM == 64), int EPI = 0, int KW = 1, bool DUAL = false, bool RAG = true>
 __global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : (SPLIT_NT_OCC3 && BM == 128 && EPI == 0) ? 3 : 2) : 1) void gemm_split_nt_kernel(SplitArgs p) {
   constexpr int MODE = SPLIT_NT_MODE, NPL = npl(MODE);
   typedef typename Frag<MODE>::type frag8;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : 
 #pragma unroll
     for (int q = 0; q < PW; ++q) rw[q] = w_piece_load<BN>(p.W, p.ldw, p.plane, p.N, n0, k0, q, tid);
 #pragma unroll
-    for (int q = 0; q < PA; ++q) a_piece_store<BM, MODE>(As, ra[0][q], KLIM(0, s0), q, tid, SA);
+    for (int q = 0; q < PA; ++q) a_piece_store<BM, MODE, RAG>(As, ra[0][q], KLIM(0, s0), q, tid, SA);
 #pragma unroll
     for (int q = 0; q < PW; ++q) w_piece_store<BN>(Bs, rw[q], q, tid);
     const int k1 = KG_AT(1), k2 = KG_AT(2);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : 
     const ASrc<DUAL> scur = a_src<DUAL>(p, kcur), snext = a_src<DUAL>(p, ka);                                       \
     const int klim = KLIM((IT) + 1, scur);                                                                          \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
-      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM, MODE>(As, ra[S][q], klim, q, tid, SA);                \
+      if (!(SPLIT_ABLATE & 2) || (IT) == 0) a_piece_store<BM, MODE, RAG>(As, ra[S][q], klim, q, tid, SA);                \
       if (!(SPLIT_ABLATE & 1)) ra[S][q] = A_LOAD(snext, q);                                                         \
     }                                                                                                               \
     _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : 
     const ASrc<DUAL> scur = a_src<DUAL>(p, kcur), snext = a_src<DUAL>(p, ka);                                       \
     const int klim = KLIM((IT) + 1, scur);                                                                          \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                                \
-      a_piece_store<BM, MODE>(An, ra[S][q], klim, q, tid, SA);                                                      \
+      a_piece_store<BM, MODE, RAG>(An, ra[S][q], klim, q, tid, SA);                                                      \
       ra[S][q] = A_LOAD(snext, q);                                                                                  \
     }                                                                                                               \
     _Pragma("unroll") for (int q = 0; q < PW; ++q) {                                                                \
@@ -790,12 +792,13 @@ __device__ __forceinline__ void tn_piece_load(const float* __restrict__ P, int l
   }
 }
 
-template <int ROWS, int MODE>
+// RAGGED false (K a multiple of 32: every production wgrad): no k row of a tile lies past K, the 32 selects per tile go
+template <int ROWS, int MODE, bool RAGGED = true>
 __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&reg)[4], int klim, float scale) {
   const int m4 = tn_m4(), k4 = tn_k4();
   bool ok[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) ok[kk] = 4 * k4 + kk < klim;
+  for (int kk = 0; kk < 4; ++kk) ok[kk] = !RAGGED || 4 * k4 + kk < klim;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = 4 * m4 + j;
@@ -811,16 +814,18 @@ __device__ __forceinline__ void tn_piece_store(unsigned char* S, const f32x4 (&r
 }
 
 // column sums of the B tile a thread holds (rows past K masked), weighted by w (0 or 1)
+template <bool RAGGED = true>
 __device__ __forceinline__ void tn_colsum_acc(const f32x4 (&reg)[4], int klim, float w, float (&cs)[4]) {
   const int k4 = tn_k4();
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const float wk = (4 * k4 + kk < klim) ? w : 0.f;
+    const float wk = (!RAGGED || 4 * k4 + kk < klim) ? w : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs[j] = fmaf(wk, reg[kk][j], cs[j]);
   }
 }
 
+template <bool RAGGED>
 __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
   constexpr int MODE = SPLIT_TN_MODE, NPL = npl(MODE);
@@ -886,9 +891,9 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   tn_piece_load(p.A, p.lda, p.K, m0, kt0 * BK, ra);
   tn_piece_load(p.B, p.ldb, p.K, n0, kt0 * BK, rb);
-  tn_piece_store<BM, MODE>(As, ra, p.K - kt0 * BK, SA);
-  tn_piece_store<BN, MODE>(Bs, rb, p.K - kt0 * BK, SB);
-  tn_colsum_acc(rb, p.K - kt0 * BK, csw, cs);
+  tn_piece_store<BM, MODE, RAGGED>(As, ra, p.K - kt0 * BK, SA);
+  tn_piece_store<BN, MODE, RAGGED>(Bs, rb, p.K - kt0 * BK, SB);
+  tn_colsum_acc<RAGGED>(rb, p.K - kt0 * BK, csw, cs);
   {
     const int k1 = (kt0 + min(1, nkt - 1)) * BK;
     tn_piece_load(p.A, p.lda, p.K, m0, k1, ra);
@@ -905,10 +910,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
       unsigned char* Bn = Bs + ((it + 1) & 1) * OP_BYTES;
       read_frags<BM, BN, MODE, true>(Ac, Bc, wm, wn, li, kh, 0, af, bf);
       const int kcur = (kt0 + min(it + 1, nkt - 1)) * BK, knext = (kt0 + min(it + 2, nkt - 1)) * BK;
-      tn_piece_store<BM, MODE>(An, ra, p.K - kcur, SA);
+      tn_piece_store<BM, MODE, RAGGED>(An, ra, p.K - kcur, SA);
       tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
-      tn_piece_store<BN, MODE>(Bn, rb, p.K - kcur, SB);
-      tn_colsum_acc(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);
+      tn_piece_store<BN, MODE, RAGGED>(Bn, rb, p.K - kcur, SB);
+      tn_colsum_acc<RAGGED>(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);
       tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
       mma_frags<TM, TN>(af, bf, acc);
       read_frags<BM, BN, MODE, true>(Ac, Bc, wm, wn, li, kh, 1, af, bf);
@@ -933,10 +938,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_tn_kernel(SplitTnArgs p) {
     __syncthreads();                                   // every wave has read tile `it`
     // unconditional like the NT kernel: one basic block, the compiler interleaves split VALU, loads and MFMAs
     const int kcur = (kt0 + min(it + 1, nkt - 1)) * BK, knext = (kt0 + min(it + 2, nkt - 1)) * BK;
-    tn_piece_store<BM, MODE>(As, ra, p.K - kcur, SA);
+    tn_piece_store<BM, MODE, RAGGED>(As, ra, p.K - kcur, SA);
     tn_piece_load(p.A, p.lda, p.K, m0, knext, ra);
-    tn_piece_store<BN, MODE>(Bs, rb, p.K - kcur, SB);
-    tn_colsum_acc(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);      // the last pass re-stages a tile already counted
+    tn_piece_store<BN, MODE, RAGGED>(Bs, rb, p.K - kcur, SB);
+    tn_colsum_acc<RAGGED>(rb, p.K - kcur, (it + 1 < nkt) ? csw : 0.f, cs);      // the last pass re-stages a tile already counted
     tn_piece_load(p.B, p.ldb, p.K, n0, knext, rb);
     mma_frags<TM, TN>(af, bf, acc);
     if (SPLIT_TN_FLUSH > 0 && (it + 1) % SPLIT_TN_FLUSH == 0) {
@@ -1124,7 +1129,14 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
 #ifndef SPLIT_NT_K256
 #define SPLIT_NT_K256 0     // 1: 64 x 128 tiles, four workgroups per CU, for the short-K products (tools/exp/gemm_ab.py)
 #endif
-  if (SPLIT_NT_K256 && blocks128 >= 384 && a.ktiles_per_split <= 8 && a.vecA) {
+#ifndef SPLIT_NT_N256
+#define SPLIT_NT_N256 0     // 1: 64 x 256 tiles for the N = 256 products: the activation tile is split ONCE for all 256 columns
+#endif
+  if (SPLIT_NT_N256 && blocks128 >= 384 && N > 128 && N <= 256 && a.vecA) {
+    a.nbx = 1; a.nby = (M + 63) / 64;
+    const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
+    hipLaunchKernelGGL((gemm_split_nt_kernel<64, 256, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else if (SPLIT_NT_K256 && blocks128 >= 384 && a.ktiles_per_split <= 8 && a.vecA) {
     a.nbx = (N + 127) / 128; a.nby = (M + 63) / 64;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
     hipLaunchKernelGGL((gemm_split_nt_kernel<64, 128, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1134,7 +1146,9 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
 #ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (tools/exp/gemm_ab.py)
 #define SPLIT_NT_DEEP128 0
 #endif
-    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.vecA && K % BK == 0)
+      hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0, 0, 1, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
@@ -1261,7 +1275,8 @@ int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const
   a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
   const long grid = (long)a.ntx * a.nty * ((a.splitk + 7) / 8 * 8);
   if (grid > 0x7fffffffL) return UNREAL_EINVAL;
-  hipLaunchKernelGGL(gemm_split_tn_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (K % BK == 0) hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
 
