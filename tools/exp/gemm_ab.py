@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = {"base": [], "n256": ["-DSPLIT_NT_N256=1"]}      # (also timed in round 4: k256 = -DSPLIT_NT_K256=1)      # (occ3 = -DSPLIT_NT_OCC3=1 is the default since its A/B)      # round 4 also timed dbuf = -DSPLIT_NT_DBUF=1,-DSPLIT_TN_DBUF=1; round 3 deep128
+VARIANTS = {"base": [], "ragged": ["-DSPLIT_FORCE_RAGGED=1"]}      # (also timed in round 4: k256 = -DSPLIT_NT_K256=1, n256 = -DSPLIT_NT_N256=1)      # (occ3 = -DSPLIT_NT_OCC3=1 is the default since its A/B)      # round 4 also timed dbuf = -DSPLIT_NT_DBUF=1,-DSPLIT_TN_DBUF=1; round 3 deep128
 # earlier rounds of this script (results in profiles/r03_gemm_nt_ablate.log): timing-only ablations "nosplit" / "noload" /
 # "nosplit_noload" = -DSPLIT_ABLATE=2 / 1 / 3 (pass them as name=-DFLAG on the command line); the direct-store epilogue
 # and the 128 x 256 tile variants were removed from the kernel after they lost
@@ -103,4 +103,42 @@ for name, M, N, K, fl in SHAPES:
         print("%-48s %-10s median %8.1f us  min %8.1f us  (%.0f fp32-equivalent TFLOP/s)" % (
             name, v, r[2], r[0], 2.0 * M * N * K / r[2] / 1e6))
     del A, Wsrc, outs, Ws
+    torch.cuda.empty_cache()
+
+# ---- wgrad (TN) shapes of the trainer: C[M,N] += A[K,M]^T B[K,N], split-K as the trainer picks it
+from unreal_amd.model.model import _splitk  # noqa: E402
+for name, M, N, K in [("fc1 wgrad   2592 x 256, K 81920", 2592, 256, 81920), ("lstm wgrad  256 x 1024, K 81920", 256, 1024, 81920),
+                      ("pc_fc1 wgrad 256 x 2592, K 81920", 256, 2592, 81920), ("fc1 wgrad   2592 x 256, K 163840", 2592, 256, 163840)]:
+    A = torch.randn(K * M, device=dev)
+    B = torch.randn(K * N, device=dev) * 0.01
+    sa, sb = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    use("base")
+    ops.absmax(K, M, A, M, sa); ops.absmax(K, N, B, N, sb)
+    sk = _splitk(M, N, K)
+    outs = {v: torch.zeros(M * N, device=dev) for v in libs}
+    res = {v: [] for v in libs}
+
+    def run_tn(v):
+        use(v)
+        ops.gemm_split_tn(M, N, K, A, M, B, N, outs[v], N, splitk=sk, a_max=sa, b_max=sb)
+
+    for v in libs:
+        run_tn(v)
+    torch.cuda.synchronize()
+    for v in libs:
+        if v != "base":
+            print("   %s: max |d| vs base %.3e (split-K atomics: order-dependent last bits)" % (v, float((outs[v] - outs["base"]).abs().max())))
+    for rnd in range(5):
+        for v in libs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run_tn(v)
+            e1.record()
+            torch.cuda.synchronize()
+            res[v].append(e0.elapsed_time(e1) / 3 * 1e3)
+    for v in libs:
+        r = sorted(res[v])
+        print("%-48s %-10s median %8.1f us  min %8.1f us  (%.0f fp32-equivalent TFLOP/s)" % (name, v, r[2], r[0], 2.0 * M * N * K / r[2] / 1e6))
+    del A, B, outs
     torch.cuda.empty_cache()

@@ -1146,7 +1146,10 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
 #ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (tools/exp/gemm_ab.py)
 #define SPLIT_NT_DEEP128 0
 #endif
-    if (a.vecA && K % BK == 0)
+#ifndef SPLIT_FORCE_RAGGED
+#define SPLIT_FORCE_RAGGED 0     // 1: always the masked instantiations (A/B of the non-ragged fast paths)
+#endif
+    if (!SPLIT_FORCE_RAGGED && a.vecA && K % BK == 0)
       hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0, 0, 1, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1275,7 +1278,7 @@ int unreal_gemm_f32_split_tn(int M, int N, int K, const float* A, int lda, const
   a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
   const long grid = (long)a.ntx * a.nty * ((a.splitk + 7) / 8 * 8);
   if (grid > 0x7fffffffL) return UNREAL_EINVAL;
-  if (K % BK == 0) hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (!SPLIT_FORCE_RAGGED && K % BK == 0) hipLaunchKernelGGL(gemm_split_tn_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(gemm_split_tn_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   return unreal_launch_status();
 }
