@@ -11,7 +11,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "exp", "build")
-VARIANTS = {"base": [], "ragged": ["-DSPLIT_FORCE_RAGGED=1"]}      # (also timed in round 4: k256 = -DSPLIT_NT_K256=1, n256 = -DSPLIT_NT_N256=1)      # (occ3 = -DSPLIT_NT_OCC3=1 is the default since its A/B)      # round 4 also timed dbuf = -DSPLIT_NT_DBUF=1,-DSPLIT_TN_DBUF=1; round 3 deep128
+VARIANTS = {"base": []}
+# round 4 timed: dbuf = -DSPLIT_NT_DBUF=1,-DSPLIT_TN_DBUF=1; occ3 = -DSPLIT_NT_OCC3=1 (adopted); k256 = -DSPLIT_NT_K256=1;
+# n256 = -DSPLIT_NT_N256=1; ragged = -DSPLIT_FORCE_RAGGED=1; and the compiler's scheduling strategies below
+for _st in ("gcn-max-ilp", "gcn-max-memory-clause", "gcn-iterative-ilp", "gcn-iterative-minreg"):
+    VARIANTS[_st.replace("gcn-", "")] = ["-mllvm", "-amdgpu-sched-strategy=" + _st]
 # earlier rounds of this script (results in profiles/r03_gemm_nt_ablate.log): timing-only ablations "nosplit" / "noload" /
 # "nosplit_noload" = -DSPLIT_ABLATE=2 / 1 / 3 (pass them as name=-DFLAG on the command line); the direct-store epilogue
 # and the 128 x 256 tile variants were removed from the kernel after they lost

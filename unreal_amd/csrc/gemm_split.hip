@@ -1149,7 +1149,12 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
 #ifndef SPLIT_FORCE_RAGGED
 #define SPLIT_FORCE_RAGGED 0     // 1: always the masked instantiations (A/B of the non-ragged fast paths)
 #endif
-    if (!SPLIT_FORCE_RAGGED && a.vecA && K % BK == 0)
+#ifndef SPLIT_NT_NORAG
+#define SPLIT_NT_NORAG 0         // 1: the 128 x 128 kernel without the "k < K" selects when K % 32 == 0.  Round 4 A/B
+#endif                           // (profiles/r04_gemm_ragged_ab.log): 5-15 % SLOWER than the masked instantiation (fewer
+                                 // instructions, worse schedule: fc1 fwd 854 vs 742 us) -- off; the wgrad kernel keeps its
+                                 // non-ragged form (0.5-3 % faster)
+    if (SPLIT_NT_NORAG && !SPLIT_FORCE_RAGGED && a.vecA && K % BK == 0)
       hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0, 0, 1, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
