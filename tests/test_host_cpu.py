@@ -183,3 +183,15 @@ def test_wgrad_splitk_is_a_multiple_of_8_at_trainer_shapes():
         sk = _splitk(M, N, K)
         assert sk % 8 == 0 and 8 <= sk <= (K + 31) // 32 // 4
     assert _splitk(256, 1024, 60) == 1 and _splitk(2592, 256, 40) == 1        # tiny test batches: no split
+
+
+def test_smoke_entry_can_import_its_test_helpers():
+    """__graft_entry__.smoke() borrows helpers from tests/test_trainer_gpu.py, importing it as `tests.test_trainer_gpu` from a
+    process whose sys.path holds the repo root only (the driver's call): every module-level import of that file must
+    resolve there (round 4: `import margins` did not)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import importlib; "
+            "m = importlib.import_module('tests.test_trainer_gpu'); assert hasattr(m, '_build') and hasattr(m.margins, 'record')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]

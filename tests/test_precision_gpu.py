@@ -31,7 +31,10 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-import margins
+try:
+    import margins
+except ImportError:            # imported as tests.<module> (__graft_entry__.smoke): tests/ itself is not on sys.path
+    from tests import margins
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

@@ -9,7 +9,10 @@ import numpy as np
 import pytest
 import torch
 
-import margins
+try:
+    import margins
+except ImportError:            # imported as tests.<module> (__graft_entry__.smoke): tests/ itself is not on sys.path
+    from tests import margins
 
 pytestmark = pytest.mark.gpu
 
