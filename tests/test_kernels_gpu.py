@@ -879,3 +879,31 @@ def test_fused_policy_maze_rollout_step_is_the_two_launch_path(ops, B):
                 b_ = rings[1].r_pc[(b * H1 + c) * 400:(b * H1 + c + 1) * 400]
                 assert torch.equal(a_, b_)
     assert int(st[0]["te"].sum()) > 0 and int(st[0]["active"].sum()) < B       # some actors did finish
+
+
+def test_encoder_fwd_is_bit_reproducible(ops):
+    """A frame's conv outputs do not depend on the launch it is part of: the same frame gives the same bits in two launches, at
+    a different position of the frame list and in a launch of a different size (the per-kernel scales come from maxima and
+    from L1 norms reduced in a fixed order -- ADVICE r3; the partial tiles of the two K halves are added in a fixed order)."""
+    rs = np.random.RandomState(3)
+    p = _enc_params(4)
+    N = 700
+    pool = rs.randint(0, 256, size=(N, 84, 84, 3)).astype(np.uint8)
+    P = {k: dev(v, torch.float32) for k, v in p.items()}
+    fr = dev(pool.reshape(-1))
+
+    def run(idx):
+        n = len(idx)
+        f2 = torch.zeros(n * 2592, device=DEV); c1 = torch.zeros(n * 6400, device=DEV)
+        ops.encoder_fwd(fr, dev(np.asarray(idx, dtype=np.int32)), 1.0 / 255.0, P["W_base_conv1"], P["b_base_conv1"],
+                        P["W_base_conv2"], P["b_base_conv2"], f2, c1)
+        return f2.view(n, 2592), c1.view(n, 6400)
+
+    a2, a1 = run(np.arange(N))
+    b2, b1 = run(np.arange(N))
+    assert torch.equal(a2, b2) and torch.equal(a1, b1)
+    perm = rs.permutation(N)
+    c2, c1_ = run(perm)
+    assert torch.equal(c2, a2[torch.as_tensor(perm, device=DEV)]) and torch.equal(c1_, a1[torch.as_tensor(perm, device=DEV)])
+    d2, d1 = run(np.arange(5))                                  # five workgroups instead of 512
+    assert torch.equal(d2, a2[:5]) and torch.equal(d1, a1[:5])
