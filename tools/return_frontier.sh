@@ -31,6 +31,8 @@ for cfg in "$@"; do
   tail -q -n 1 gpurun_out/return/${TAG}_b${B}_g${G}_s*/stdout.log
   python3 tools/return_eval.py --cap "${CAP:-2000}" "${dirs[@]}" >> gpurun_out/return/eval_${TAG}_${STAMP}.jsonl 2>> gpurun_out/return/eval_${TAG}_${STAMP}.err || { rc=$?; tail -n 5 gpurun_out/return/eval_${TAG}_${STAMP}.err; }
   rm -f gpurun_out/return/${TAG}_b${B}_g${G}_s*/ckpt-*.npz
+  # resume states are 15 MB each and gpurun refuses to copy back more than 64 MiB in total: keep them only when asked to
+  [ "${KEEP_STATE:-0}" = "1" ] || rm -f gpurun_out/return/${TAG}_b${B}_g${G}_s*/state.pt
   echo "[frontier] $cfg done rc=$rc at $(date +%T)"
 done
 exit $rc
