@@ -1126,37 +1126,53 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
     a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
   }
   const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
+  // Experiment knobs of round 4 (tools/exp/gemm_ab.py, profiles/r04_ab_summary.md; all default 0, none of their kernels is
+  // instantiated in the product build): SPLIT_NT_N256 = 64 x 256 tiles for the N = 256 products (0.89x), SPLIT_NT_K256 =
+  // 64 x 128 tiles at four workgroups per CU for the short-K products (0.89x), SPLIT_NT_NORAG = the 128 x 128 kernel without
+  // its "k < K" selects when K % 32 == 0 (0.87-0.95x: fewer instructions, worse schedule); SPLIT_FORCE_RAGGED = the masked
+  // instantiations everywhere (A/B of the wgrad kernel's non-ragged form, which is kept: +1 %).
 #ifndef SPLIT_NT_K256
-#define SPLIT_NT_K256 0     // 1: 64 x 128 tiles, four workgroups per CU, for the short-K products (tools/exp/gemm_ab.py)
+#define SPLIT_NT_K256 0
 #endif
 #ifndef SPLIT_NT_N256
-#define SPLIT_NT_N256 0     // 1: 64 x 256 tiles for the N = 256 products: the activation tile is split ONCE for all 256 columns
+#define SPLIT_NT_N256 0
 #endif
-  if (SPLIT_NT_N256 && blocks128 >= 384 && N > 128 && N <= 256 && a.vecA) {
+#ifndef SPLIT_FORCE_RAGGED
+#define SPLIT_FORCE_RAGGED 0
+#endif
+#ifndef SPLIT_NT_NORAG
+#define SPLIT_NT_NORAG 0
+#endif
+#ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (round 3: 0.97-1.02x)
+#define SPLIT_NT_DEEP128 0
+#endif
+  bool launched = false;
+#if SPLIT_NT_N256
+  if (!launched && blocks128 >= 384 && N > 128 && N <= 256 && a.vecA) {
     a.nbx = 1; a.nby = (M + 63) / 64;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
     hipLaunchKernelGGL((gemm_split_nt_kernel<64, 256, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  } else if (SPLIT_NT_K256 && blocks128 >= 384 && a.ktiles_per_split <= 8 && a.vecA) {
+    launched = true;
+  }
+#endif
+#if SPLIT_NT_K256
+  if (!launched && blocks128 >= 384 && a.ktiles_per_split <= 8 && a.vecA) {
     a.nbx = (N + 127) / 128; a.nby = (M + 63) / 64;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
     hipLaunchKernelGGL((gemm_split_nt_kernel<64, 128, true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    launched = true;
+  }
+#endif
+  if (launched) {
   } else if (blocks128 >= 384) {
     a.nbx = (N + 127) / 128; a.nby = (M + 127) / 128;
     const int grid = a.splitk * a.nbx * ((a.nby + 7) / 8 * 8);
-#ifndef SPLIT_NT_DEEP128      // A tiles of the 128 x 128 kernel two K tiles ahead (tools/exp/gemm_ab.py)
-#define SPLIT_NT_DEEP128 0
-#endif
-#ifndef SPLIT_FORCE_RAGGED
-#define SPLIT_FORCE_RAGGED 0     // 1: always the masked instantiations (A/B of the non-ragged fast paths)
-#endif
-#ifndef SPLIT_NT_NORAG
-#define SPLIT_NT_NORAG 0         // 1: the 128 x 128 kernel without the "k < K" selects when K % 32 == 0.  Round 4 A/B
-#endif                           // (profiles/r04_gemm_ragged_ab.log): 5-15 % SLOWER than the masked instantiation (fewer
-                                 // instructions, worse schedule: fc1 fwd 854 vs 742 us) -- off; the wgrad kernel keeps its
-                                 // non-ragged form (0.5-3 % faster)
-    if (SPLIT_NT_NORAG && !SPLIT_FORCE_RAGGED && a.vecA && K % BK == 0)
+#if SPLIT_NT_NORAG
+    if (!SPLIT_FORCE_RAGGED && a.vecA && K % BK == 0)
       hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0, 0, 1, false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else
+#endif
+    if (a.vecA) hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, true, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((gemm_split_nt_kernel<128, 128, false, SPLIT_NT_DEEP128 != 0>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {
     a.nbx = (N + 63) / 64; a.nby = (M + 63) / 64;
