@@ -52,6 +52,23 @@ def _stage_frames(dst, frames):
         f.result()
 
 
+# Staging and PCIe as a pipeline (round 4): the frames of a (half-)batch go to the pinned buffer in STAGE_CHUNKS pieces and the
+# H2D copy of a piece is issued as soon as the piece is staged, so the copy engine moves piece i while the host threads
+# stage piece i + 1 -- a step's ingest costs ~max(host memcpy, PCIe) instead of their sum.  1 = the round-3 schedule.
+STAGE_CHUNKS = int(os.environ.get("UNREAL_STAGE_CHUNKS", 4))
+
+
+def _stage_and_copy(h_frames, frames, staged):
+    """h_frames (pinned [n,84,84,3]) <- frames, staged (device bytes) <- h_frames, piece by piece on the current stream."""
+    n = h_frames.shape[0]
+    chunks = max(1, min(STAGE_CHUNKS, n // 64))
+    step = (n + chunks - 1) // chunks
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        _stage_frames(h_frames[a:b], frames[a:b])
+        staged[a * ops.FRAME_BYTES:b * ops.FRAME_BYTES].copy_(h_frames[a:b].view(-1), non_blocking=True)
+
+
 class HostFedEnvironment(object):
     def __init__(self, simulator, batch, history_size, device="cuda:0", action_size=6, clip_reward=True,
                  frame_max=255.0, objective_size=0, reward_divisor=1.0):
@@ -90,8 +107,7 @@ class HostFedEnvironment(object):
         self._h2d_done.record()
 
     def _stage(self, frames):
-        _stage_frames(self._h_frames, frames)
-        self._staged.copy_(self._h_frames.view(-1), non_blocking=True)
+        _stage_and_copy(self._h_frames, frames, self._staged)
 
     def _stage_objective(self, objectives, active):
         self._h_obj.copy_(torch.from_numpy(np.ascontiguousarray(objectives, dtype=np.float32)))
@@ -180,7 +196,8 @@ class HostFedEnvironment(object):
         rewards = rewards[b0:b1]
         if self.reward_divisor != 1.0:                  # indoor_environment.py:111
             rewards = (rewards.astype(np.float64) / self.reward_divisor).astype(np.float32)
-        _stage_frames(p["h_frames"], frames[b0:b1])
+        with torch.cuda.stream(p["stream"]):           # H2D of every staged piece starts at once, on the part's own stream
+            _stage_and_copy(p["h_frames"], frames[b0:b1], p["staged"])
         p["h_rewards"].copy_(torch.from_numpy(np.ascontiguousarray(rewards, dtype=np.float32)))
         p["h_terminals"].copy_(torch.from_numpy(np.ascontiguousarray(terminals[b0:b1], dtype=np.int32)))
         if self.objective_size:
@@ -188,8 +205,7 @@ class HostFedEnvironment(object):
 
     def part_ingest(self, k, actions, active, out_reward, out_terminal, reset_on_terminal=True, track_score=False):
         """On part k's stream: H2D of the staged part + the ring commit kernel for its actors."""
-        p = self.parts[k]
-        p["staged"].copy_(p["h_frames"].view(-1), non_blocking=True)
+        p = self.parts[k]                              # (the frames' H2D copies were issued by part_host_step, piece by piece)
         p["rewards"].copy_(p["h_rewards"], non_blocking=True)
         p["terminals"].copy_(p["h_terminals"], non_blocking=True)
         ops.hostfed_step(p["ring"], p["staged"], actions, p["rewards"], p["terminals"], active, out_reward, out_terminal,
