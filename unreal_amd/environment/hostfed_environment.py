@@ -52,10 +52,13 @@ def _stage_frames(dst, frames):
         f.result()
 
 
-# Staging and PCIe as a pipeline (round 4): the frames of a (half-)batch go to the pinned buffer in STAGE_CHUNKS pieces and the
-# H2D copy of a piece is issued as soon as the piece is staged, so the copy engine moves piece i while the host threads
-# stage piece i + 1 -- a step's ingest costs ~max(host memcpy, PCIe) instead of their sum.  1 = the round-3 schedule.
-STAGE_CHUNKS = int(os.environ.get("UNREAL_STAGE_CHUNKS", 4))
+# Staging and PCIe as a pipeline (round 4 experiment, UNREAL_STAGE_CHUNKS > 1): the frames of a (half-)batch go to the pinned
+# buffer in pieces and the H2D copy of a piece is issued as soon as the piece is staged, so that the copy engine moves piece i
+# while the host threads stage piece i + 1.  Measured (tools/bench_hostfed.py, profiles/r04_hostfed.md): SLOWER -- 4096 actors
+# 1.37 M env-steps/s with one piece, 0.89 M with four, 0.63 M with eight (per-piece thread-pool joins and copy submissions, and
+# the DMA engine reading the pinned buffer while eight threads write it share the host's memory bandwidth).  Default 1 = one
+# staging copy, one H2D copy per (half-)batch and step.
+STAGE_CHUNKS = int(os.environ.get("UNREAL_STAGE_CHUNKS", 1))
 
 
 def _stage_and_copy(h_frames, frames, staged):
