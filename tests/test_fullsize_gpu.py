@@ -431,11 +431,17 @@ def test_fullshape_split_gemms_not_worse_than_fp32_mfma_on_live_operands(branche
         M_, N_ = A.shape[1], Bm.shape[1]
         R = ref_tn(A, Bm)
         sk = _splitk(M_, N_, rows)
-        C = torch.zeros(M_, N_, device=DEV)
-        ops.gemm_split_tn(M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C, N_, splitk=sk)
-        C32 = torch.zeros(M_, N_, device=DEV)
-        ops.gemm(True, False, M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C32, N_, flags=ops.GEMM_ATOMIC, splitk=sk)
-        (r16, p16), (r32, p32) = _err_stats(C, R), _err_stats(C32, R)
+        # both kernels add their K slabs with fp32 atomics: the order, and with it the last bits and where the tail lands,
+        # differs from launch to launch (the p99.99 ratio of one pair of launches moves by +-0.04) -- median of three launches
+        s16, s32 = [], []
+        for _ in range(3):
+            C = torch.zeros(M_, N_, device=DEV)
+            ops.gemm_split_tn(M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C, N_, splitk=sk)
+            C32 = torch.zeros(M_, N_, device=DEV)
+            ops.gemm(True, False, M_, N_, rows, A, A.stride(0), Bm, Bm.stride(0), C32, N_, flags=ops.GEMM_ATOMIC, splitk=sk)
+            s16.append(_err_stats(C, R)); s32.append(_err_stats(C32, R))
+        med = lambda v, k: sorted(x[k] for x in v)[1]
+        (r16, p16), (r32, p32) = (med(s16, 0), med(s16, 1)), (med(s32, 0), med(s32, 1))
         margins.record("live gate: " + name + " rms", r16 / r32, "1 x unreal_gemm_f32")
         margins.record("live gate: " + name + " p99.99", p16 / p32, "1 x unreal_gemm_f32")
         assert r16 <= r32 and p16 <= p32, (name, r16, r32, p16, p32)
