@@ -189,6 +189,14 @@ int unreal_split_bf16x3(int rows, int cols, const float* src, int ld_src, int tr
 /* fp16x2 shadow: dst[0] = hi, dst[1] = lo of src * 2^k, k from w_absmax (a slot that already holds max |src| over the
  * WHOLE matrix the consuming GEMM multiplies by).  Same layouts / row_perm as above.  Refreshed after every RMSProp step /
  * checkpoint restore. */
+/* Every weight shadow of a network in one pass (round 4): `abs_descs` = n_abs records {const float* src; float* wmax; long n;
+ * long block0} (contiguous matrices; block0 = first block of the record in a grid of 8192-float blocks, ascending), `split_descs`
+ * = n_split records {const float* src; uint16_t* dst; const float* wmax; long rows, cols, ld_src, transpose, row_perm, ld_dst,
+ * plane, tiles_x, block0} (32 x 32 tiles; the arguments of unreal_split_f16x2).  The wmax slots must be zeroed by the caller;
+ * element for element the arithmetic of unreal_absmax_f32 + unreal_split_f16x2 (identical bits), in two launches instead of
+ * three per matrix.  Both tables are device memory. */
+int unreal_shadow_refresh_multi(const void* abs_descs, int n_abs, int abs_blocks, const void* split_descs, int n_split,
+                                int split_blocks, void* stream);
 int unreal_split_f16x2(int rows, int cols, const float* src, int ld_src, int transpose, int row_perm, uint16_t* dst,
                        int ld_dst, long plane_stride, const float* w_absmax, void* stream);
 /* row_perm = 1 (1024 output rows only): LSTM gate interleave, output row of column n = g*256 + u of the kernel is

@@ -236,3 +236,41 @@ def test_fused_lstm_step_matches_unfused_and_fp64(rows):
     np.testing.assert_allclose(g1.cpu().numpy().reshape(rows, 1024), np.concatenate([i, j, f, o], 1), atol=1e-5, rtol=1e-5)
     with pytest.raises(ValueError):
         ops.lstm_step_fwd(rows, dev(h_prev).view(-1), sh_nat, g1, dev(bias), dev(c_prev).view(-1), c1, h1)
+
+
+def test_shadow_set_refresh_is_the_per_matrix_refresh():
+    """ops.ShadowSet (one fill + unreal_shadow_refresh_multi: every matrix's maximum, then every matrix's planes) leaves the
+    same bits as fill + unreal_absmax_f32 + unreal_split_f16x2 per matrix -- for every shadow kind the model keeps (transposed,
+    natural, row offset, gate-interleaved rows, the whole LSTM kernel in two pieces) -- and follows the weights when they change."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(5)
+    K_x = 261
+    Wfc = dev(rs.uniform(-.02, .02, 2592 * 256)); Wl = dev(rs.uniform(-.07, .07, (K_x + 256) * 1024)); Wpc = dev(rs.uniform(-3, 3, 256 * 2592))
+    specs = [("sw", Wfc, 2592, 256, 256, True, 0, 0), ("sw", Wfc, 2592, 256, 256, False, 0, 0), ("lk", Wl, K_x),
+             ("sw", Wl, 256, 1024, 1024, False, K_x * 1024, 0), ("sw", Wl, 256, 1024, 1024, False, 0, 0),
+             ("sw", Wl, K_x, 1024, 1024, True, 0, 0), ("sw", Wl, 256, 1024, 1024, True, K_x * 1024, 1),
+             ("sw", Wpc, 256, 2592, 2592, True, 0, 0), ("sw", Wpc, 256, 2592, 2592, False, 0, 0)]
+
+    def make(ss):
+        out = []
+        for sp in specs:
+            kw = dict(wmax=ss.slot(), defer=True) if ss is not None else {}
+            if sp[0] == "lk":
+                m = ops.LstmKernelShadow(sp[1], sp[2], **kw)
+            else:
+                m = ops.SplitWeights(sp[1], sp[2], sp[3], sp[4], sp[5], offset=sp[6], row_perm=sp[7], **kw)
+            out.append(ss.add(m) if ss is not None else m)
+        return out
+
+    ss = ops.ShadowSet(DEV, 12)
+    fused = make(ss)
+    ss.refresh()
+    single = make(None)
+    for round_ in range(2):
+        for a, b in zip(fused, single):
+            assert torch.equal(a.wmax, b.wmax) and float(a.wmax[0]) > 0
+            assert torch.equal(a.planes, b.planes)
+        Wfc.mul_(3.0); Wl.add_(0.01); Wpc.mul_(0.25)            # an optimiser step later
+        ss.refresh()
+        for m in single:
+            m.refresh()

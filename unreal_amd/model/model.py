@@ -227,29 +227,43 @@ class UnrealModel(object):
         if self._shadow is None:
             p, A = self.p, self._action_size
             K_x = self.K_x
-            S = ops.SplitWeights
+            # every shadow's absmax slot lives in ONE tensor and all of them are refreshed by one fill + two launches
+            # (ops.ShadowSet; per matrix it was fill + maximum + split: ~28 launches in front of every learner pass)
+            ss = ops.ShadowSet(self._device, 12)
+            S = lambda *a, **k: ss.add(ops.SplitWeights(*a, wmax=ss.slot(), defer=True, **k))
             sh = dict(fc1_fwd=S(p["W_base_fc1"], 2592, 256, 256, True),
                       fc1_dgrad=S(p["W_base_fc1"], 2592, 256, 256, False))
             if self._use_lstm:
                 W = p["lstm_kernel"]
-                sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
-                          lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1),   # gate-interleaved
-                          lstm_xh_fwd=ops.LstmKernelShadow(W, K_x),              # whole kernel, single-step launches
+                sh.update(lstm_xh_fwd=ss.add(ops.LstmKernelShadow(W, K_x, wmax=ss.slot(), defer=True)),   # whole kernel, single-step launches
                           lstm_h_dgrad=S(W, 256, 1024, 1024, False, offset=K_x * 1024),
                           lstm_fc_dgrad=S(W, 256, 1024, 1024, False))
+                if self.hoist_lstm_x:        # the hoisted schedule's input / recurrent halves (off: nothing reads them)
+                    sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
+                              lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1))   # gate-interleaved
             if self._use_pixel_change:
                 sh.update(pc_fc1_fwd=S(p["W_pc_fc1"], 256, 2592, 2592, True),
                           pc_fc1_dgrad=S(p["W_pc_fc1"], 256, 2592, 2592, False))
-            self._shadow = sh
-            return
-        for w in self._shadow.values():
-            w.refresh()
+            self._shadow, self._shadow_set = sh, ss
+        self._shadow_set.refresh()
 
     @property
     def shadow(self):
         if self._shadow is None:
             self.refresh_shadows()
         return self._shadow
+
+    def _hoist_shadows(self):
+        """The hoisted LSTM schedule's two shadows, made on first use (hoist_lstm_x flipped on after construction, or a caller
+        that runs lstm_step(fused_x=False) by hand)."""
+        sh = self.shadow
+        if "lstm_x_fwd" not in sh:
+            ss, W, K_x = self._shadow_set, self.p["lstm_kernel"], self.K_x
+            S = lambda *a, **k: ss.add(ops.SplitWeights(*a, wmax=ss.slot(), defer=True, **k))
+            sh.update(lstm_x_fwd=S(W, K_x, 1024, 1024, True),
+                      lstm_h_fwd=S(W, 256, 1024, 1024, True, offset=K_x * 1024, row_perm=1))
+            ss.refresh()
+        return sh
 
     # -- parameters ---------------------------------------------------------------------------------
     def _init_weights(self, seed):
@@ -367,7 +381,7 @@ class UnrealModel(object):
         if own:
             ops.absmax(1, 1, s_fc, 1, ws.s_x)
         if lstm_x:
-            ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, sh["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024,
+            ops.gemm_split_nt(nrows, 1024, self.K_x, xcat, self.xld, self._hoist_shadows()["lstm_x_fwd"], ws.gates[row0 * 1024:], 1024,
                               a_max=ops.absmax(nrows, self.K_x, xcat, self.xld, self.new_slot()))
 
     def lstm_step(self, ws, t, B, b0=0, nrows=None, fused_x=False):
@@ -384,7 +398,7 @@ class UnrealModel(object):
                               ws.c[(t * B + b0) * 256:], ws.h[(t * B + b0) * 256:],
                               x=ws.xcat[(t * B + b0) * self.xld:], ldx=self.xld, Kx=self.K_x, x_max=ws.s_x_cur)
             return
-        ops.lstm_step_fwd(n, h_prev, self.shadow["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[(t * B + b0) * 256:],
+        ops.lstm_step_fwd(n, h_prev, self._hoist_shadows()["lstm_h_fwd"], g_t, p["lstm_bias"], c_prev, ws.c[(t * B + b0) * 256:],
                           ws.h[(t * B + b0) * 256:])
 
     def features(self, ws, row0=0):

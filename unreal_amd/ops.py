@@ -406,15 +406,27 @@ class SplitWeights:
     w * 2^k, k from the matrix's absmax slot `wmax`), rows padded with zeros to a multiple of 32 k.  `refresh()` re-reduces
     the maximum and re-splits from the live fp32 weights (after an optimiser step)."""
 
-    def __init__(self, src, rows, cols, ld_src, transpose, offset=0, row_perm=0):
+    def __init__(self, src, rows, cols, ld_src, transpose, offset=0, row_perm=0, wmax=None, defer=False):
+        """wmax: a one-float view the caller owns (ShadowSet keeps the slots of all its shadows in one tensor, zeroed with one
+        fill); defer: do not split now (a ShadowSet refreshes all its members together)."""
         self.src, self.rows, self.cols, self.ld_src, self.transpose, self.offset = src, rows, cols, ld_src, transpose, offset
         self.row_perm = row_perm
         self.N, self.K = (cols, rows) if transpose else (rows, cols)
         self.ldw = (self.K + 31) // 32 * 32
         self.plane = self.N * self.ldw
         self.planes = torch.zeros(2 * self.plane, dtype=torch.int16, device=src.device)
-        self.wmax = torch.zeros(1, dtype=torch.float32, device=src.device)
-        self.refresh()
+        self.wmax = torch.zeros(1, dtype=torch.float32, device=src.device) if wmax is None else wmax
+        if not defer:
+            self.refresh()
+
+    def multi_descs(self):
+        """-> (abs record or None, [split records]) for ShadowSet: pointers and sizes as Python ints."""
+        if self.ld_src != self.cols:
+            return None, None                         # a column window: not contiguous, refreshed by itself
+        src = self.src.data_ptr() + 4 * self.offset
+        return ((src, self.wmax.data_ptr(), self.rows * self.cols),
+                [(src, self.planes.data_ptr(), self.wmax.data_ptr(), self.rows, self.cols, self.ld_src, int(bool(self.transpose)),
+                  int(self.row_perm), self.ldw, self.plane)])
 
     def refresh(self):
         self.wmax.zero_()
@@ -444,15 +456,22 @@ class LstmKernelShadow:
     multiplies it: planes[t][1024][pad32(K_x) + 256] -- input rows, zero padding to a K tile, recurrent rows; one scale
     (absmax slot) for the whole kernel."""
 
-    def __init__(self, kernel, K_x):
+    def __init__(self, kernel, K_x, wmax=None, defer=False):
         self.src, self.K_x, self.row_perm = kernel, K_x, 1
         self.kxpad = (K_x + 31) // 32 * 32
         self.N, self.K = 1024, self.kxpad + 256
         self.ldw = self.K
         self.plane = self.N * self.ldw
         self.planes = torch.zeros(2 * self.plane, dtype=torch.int16, device=kernel.device)
-        self.wmax = torch.zeros(1, dtype=torch.float32, device=kernel.device)
-        self.refresh()
+        self.wmax = torch.zeros(1, dtype=torch.float32, device=kernel.device) if wmax is None else wmax
+        if not defer:
+            self.refresh()
+
+    def multi_descs(self):
+        src, dst, wm = self.src.data_ptr(), self.planes.data_ptr(), self.wmax.data_ptr()
+        return ((src, wm, (self.K_x + 256) * 1024),
+                [(src, dst, wm, self.K_x, 1024, 1024, 1, 1, self.ldw, self.plane),
+                 (src + 4 * self.K_x * 1024, dst + 2 * self.kxpad, wm, 256, 1024, 1024, 1, 1, self.ldw, self.plane)])
 
     def refresh(self):
         self.wmax.zero_()
@@ -460,6 +479,55 @@ class LstmKernelShadow:
         split_f16x2(self.K_x, 1024, self.src, 1024, True, self.planes, self.ldw, self.plane, self.wmax, 1)
         split_f16x2(256, 1024, self.src[self.K_x * 1024:], 1024, True, self.planes[self.kxpad:], self.ldw, self.plane,
                     self.wmax, 1)
+
+
+class ShadowSet(object):
+    """All weight shadows of a network refreshed together: one fill of their absmax slots, one launch that reduces every
+    matrix's maximum, one that writes every matrix's planes (unreal_shadow_refresh_multi) -- instead of fill + maximum +
+    split per matrix.  `make` is called with a factory: wmax_view = slots[i:i + 1] for shadow i."""
+
+    def __init__(self, device, n_shadows):
+        self.device = device
+        self.slots = torch.zeros(n_shadows, dtype=torch.float32, device=device)
+        self.members, self._descs = [], None
+
+    def slot(self):
+        i = len(self.members)
+        if i >= self.slots.numel():
+            raise RuntimeError("ShadowSet: more shadows than slots")
+        return self.slots[i:i + 1]
+
+    def add(self, shadow):
+        self.members.append(shadow)
+        self._descs = None
+        return shadow
+
+    def _build(self):
+        abs_rows, split_rows, singles = [], [], []
+        ab, sb = 0, 0
+        for m in self.members:
+            a, sp = m.multi_descs()
+            if a is None:
+                singles.append(m)
+                continue
+            abs_rows.append([a[0], a[1], a[2], ab])
+            ab += (a[2] + 8191) // 8192
+            for r in sp:
+                tiles_x = (r[4] + 31) // 32
+                split_rows.append(list(r) + [tiles_x, sb])
+                sb += tiles_x * ((r[3] + 31) // 32)
+        mk = lambda rows: torch.tensor(rows, dtype=torch.int64).to(self.device).contiguous()
+        self._descs = (mk(abs_rows), len(abs_rows), ab, mk(split_rows), len(split_rows), sb, singles)
+
+    def refresh(self):
+        if self._descs is None:
+            self._build()
+        a, na, ab, sp, ns, sb, singles = self._descs
+        self.slots.zero_()
+        if na:
+            _call("unreal_shadow_refresh_multi", ptr(a), na, ab, ptr(sp), ns, sb)
+        for m in singles:                    # (zeroed above; their own refresh would zero the slot again: harmless)
+            m.refresh()
 
 
 def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags=0, splitk=1, a_max=None, c_max=None):
