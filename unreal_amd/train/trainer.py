@@ -594,9 +594,8 @@ class Trainer(object):
         # bootstrap frames of both samples (zero LSTM state, model.py:395,461)
         bw = self.boot2_ws
         ops.gather_i32(self.last2, self.map_boot, bw.frame_idx[:2 * B])
-        if self.use_lstm:
-            bw.c0.zero_()
-            bw.h0.zero_()
+        # (boot2_ws / aux2_ws belong to this pass alone and nothing ever writes their c0 / h0: they are the zero state they
+        # were allocated as -- model.py:395,461 -- so the four fills per pass the per-branch schedule needs are not issued)
         feat, ld = net.trunk_forward(self.ring, bw, 1, 2 * B, lar_from_ring=True, save_c1=False)
         s_bhp = net.new_slot()             # max of the bootstrap frames' hp: committed by the pc_fc1 GEMM
         net.pc_head_forward(B, feat, 2 * ld, self.boot_hp, ws=self.boot2_ws, hp_max=s_bhp)
@@ -608,9 +607,6 @@ class Trainer(object):
         # the 2B sequences through the trunk
         ws = self.aux2_ws
         ops.gather_i32(self.seq_idx_cat, self.map_seq, ws.frame_idx[:2 * rows])
-        if self.use_lstm:
-            ws.c0.zero_()
-            ws.h0.zero_()
         feat, ld = net.trunk_forward(self.ring, ws, Ta, 2 * B, lar_from_ring=True, save_c1=True)
         d_feat = gws.d_feat
         # pixel-control head on the even rows
