@@ -265,6 +265,15 @@ int unreal_pc_deconv_fwd(int N, int A, const float* hp, const float* hp_absmax, 
 int unreal_pc_deconv_bwd(int N, int A, const float* hp, const float* hp_absmax, const float* d_dec, const float* ddec_absmax,
                          const float* Wv, const float* Wa, float* d_hp, float* dhp_absmax /*nullable absmax slot: max |d_hp|*/,
                          float* dWv, float* dbv, float* dWa, float* dba, void* stream);
+/* The training pass of the head (model.py:411-443 forward, 542-557 loss, and their gradients) in ONE launch: what
+ * unreal_pc_deconv_fwd (training mode) followed by unreal_pc_deconv_bwd computes, with d_dec kept on chip -- its fp16 hi + lo
+ * planes take each FRAME's own power-of-two scale (max |dL/dQ| of the frame) instead of the launch's.  *loss and the four
+ * parameter gradients are accumulated; d_dec is a nullable [N][400][1+A] output for inspection. */
+int unreal_pc_deconv_train(int N, int A, const float* hp, const float* hp_absmax, const float* Wv, const float* bv,
+                           const float* Wa, const float* ba, const int* action, const float* target, const int* mask,
+                           float lambda, float grad_scale, float* loss, float* d_hp,
+                           float* dhp_absmax /*nullable absmax slot: max |d_hp|*/, float* dWv, float* dbv, float* dWa,
+                           float* dba, float* d_dec, void* stream);
 
 /* ---- optimiser (train/rmsprop_applier.py:38-43, 83-93, 121) ---------------------------------------- */
 int unreal_grad_norm(const float* grad, long n, float* scratch /*256 floats*/, float* norm_out, void* stream);

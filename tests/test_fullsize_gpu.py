@@ -231,6 +231,7 @@ def _check_trunk(net, tr, ws, b, n, c0, h0, p64, what, btot=None):
 def branches(trained):
     """Roll out once more at full size and leave the BASE branch's activations / gradient temporaries in place."""
     flags, net, tr, _, _ = trained
+    tr.keep_d_dec = True          # the one-launch pixel-control pass keeps d_dec on chip: ask for its inspection copy
     net.refresh_shadows()
     tr._rollout()
     net.grads.flat.zero_()

@@ -620,7 +620,7 @@ def test_colsum_relu_mask_lar(ops):
 # ---------------------------------------------------------------------------------------------------
 # pixel-control head
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,A", [(1, 4), (9, 4), (130, 4), (7, 6), (5, 3)])
+@pytest.mark.parametrize("N,A", [(1, 4), (9, 4), (130, 4), (1300, 4), (7, 6), (5, 3), (6, 7)])
 def test_pc_deconv_fwd_bwd(ops, N, A):
     rs = np.random.RandomState(N * 10 + A)
     lam, gs = 0.05, 0.25
@@ -663,6 +663,27 @@ def test_pc_deconv_fwd_bwd(ops, N, A):
     close(dWa.reshape(4, 4, A, 32), Wa.grad, what="dWa", **tol)
     close(dbv, bv.grad, what="dbv", **tol)
     close(dba, ba.grad, what="dba", **tol)
+    # the same pass in one launch (d_dec kept on chip, per-frame scale): the same fp64 reference at the same bars; its
+    # optional d_dec output is the forward kernel's bit for bit
+    d_dec2 = torch.zeros_like(d_dec); ls2 = torch.zeros(1, device=DEV); d_hp2 = torch.full_like(d_hp, 7.0)
+    dWv2 = torch.zeros(512, device=DEV); dbv2 = torch.zeros(1, device=DEV)
+    dWa2 = torch.zeros(512 * A, device=DEV); dba2 = torch.zeros(A, device=DEV); mx = torch.zeros(1, device=DEV)
+    ops.pc_deconv_train(N, A, d["hp"], d["Wv"], d["bv"], d["Wa"], d["ba"], dev(act, torch.int32), dev(tgt.reshape(-1), f32),
+                        dev(mask), lam, gs, ls2, d_hp2, dWv2, dbv2, dWa2, dba2, dhp_max=mx, d_dec=d_dec2)
+    assert torch.equal(d_dec2, d_dec)
+    close(ls2, [float(loss) * gs], atol=1e-4, rtol=1e-4, what="pc loss (one launch)")
+    close(d_hp2.reshape(N, 9, 9, 32), hp.grad * (hp.detach() > 0), what="d_hp (one launch)", **tol)
+    close(dWv2.reshape(4, 4, 1, 32), Wv.grad, what="dWv (one launch)", **tol)
+    close(dWa2.reshape(4, 4, A, 32), Wa.grad, what="dWa (one launch)", **tol)
+    close(dbv2, bv.grad, what="dbv (one launch)", **tol)
+    close(dba2, ba.grad, what="dba (one launch)", **tol)
+    assert float(mx) == float(d_hp2.abs().max())
+    # without the inspection output: identical results
+    ls3 = torch.zeros(1, device=DEV); d_hp3 = torch.zeros_like(d_hp)
+    g3 = [torch.zeros(512, device=DEV), torch.zeros(1, device=DEV), torch.zeros(512 * A, device=DEV), torch.zeros(A, device=DEV)]
+    ops.pc_deconv_train(N, A, d["hp"], d["Wv"], d["bv"], d["Wa"], d["ba"], dev(act, torch.int32), dev(tgt.reshape(-1), f32),
+                        dev(mask), lam, gs, ls3, d_hp3, *g3)
+    assert torch.equal(d_hp3, d_hp2)
 
 
 def test_pc_vr_return_scans(ops):

@@ -55,7 +55,7 @@ def _exps(n):
 
 def _check_bound(what, err, S, floor, c=C_REL):
     """(1): err, S tensors (float64, device); floor a Python float or a broadcastable tensor."""
-    bound = c * U22 * S + floor
+    bound = (c * U22 * S + floor).clamp_min(1e-300)       # an output whose bound is 0 (a masked frame) must be exactly 0
     ratio = float((err / bound).max())
     # how much of the worst element's bar is the relative part (1 = pure 2^-22 sum|a||b|; ~0 = on the absolute floor)
     k = int(torch.argmax(err / bound))
@@ -375,6 +375,66 @@ def test_pc_deconv_bwd_dynamic_range(which, A):
     _check_bound(tag + " dW", (got_dW - r_dW).abs(), s_dW, U38 * ddmax * hpmax * 81 * N)
     got_db = torch.cat([dbv, dba]).double()
     _check_bound(tag + " db", (got_db - r_db).abs(), s_db, 0.0)
+
+
+@pytest.mark.parametrize("which", ["plain", "ddrows", "hprows"])
+@pytest.mark.parametrize("A", [4, 3])
+def test_pc_deconv_train_dynamic_range(which, A):
+    """unreal_pc_deconv_train (forward loss + backward in one launch, d_dec on chip under each FRAME's own scale): d_dec
+    is the forward kernel's bit for bit (tests/test_kernels_gpu.py), so the backward half is held to (1) against the fp64
+    backward of the d_dec the launch itself reports -- with the absolute floor taken PER FRAME (2^-38 of that frame's
+    max |d_dec|): frames whose targets sit 2^0..2^-30 from their Q (ddrows) keep their relative accuracy, which the
+    two-launch path (one scale per launch) does not promise.  hprows: the frames' hp rows at 2^0..2^-30."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(7 * A + len(which))
+    N, lam, gs = 93, 0.05, 0.25
+    hp = np.maximum(rs.standard_normal((N, 32, 9, 9)), 0)
+    if which == "hprows":
+        hp *= 2.0 ** -_exps(N)[:, None, None, None]
+    hpd = dev32(hp.transpose(0, 2, 3, 1)); hp64 = hpd.double().permute(0, 3, 1, 2)
+    mk = lambda *s: dev32(rs.uniform(-.1, .1, s))
+    Wv, Wa, bv, ba = mk(4, 4, 1, 32), mk(4, 4, A, 32), mk(1), mk(A)
+    Wcat = torch.cat([Wv.double().permute(3, 2, 0, 1), Wa.double().permute(3, 2, 0, 1)], 1).contiguous()   # [32,1+A,4,4]
+    act = rs.randint(0, A, N); mask = (rs.rand(N) < 0.9).astype(np.int32)
+    pre = F.conv_transpose2d(hp64, Wcat, torch.cat([bv, ba]).double(), stride=2)        # [N,1+A,20,20]
+    v, a = torch.relu(pre[:, :1]), torch.relu(pre[:, 1:])
+    q = v + a - a.mean(1, keepdim=True)
+    qa = q[torch.arange(N), torch.as_tensor(act, device=DEV)]                            # [N,20,20]
+    if which == "ddrows":
+        tgt = (qa + torch.as_tensor(rs.standard_normal((N, 20, 20)) * 2.0 ** -_exps(N)[:, None, None], device=DEV)).float()
+    else:
+        tgt = dev32(rs.uniform(0, 1, (N, 20, 20)))
+    d_dec = torch.zeros(N * 400 * (1 + A), device=DEV); ls = torch.zeros(1, device=DEV); d_hp = torch.zeros(N * 2592, device=DEV)
+    dWv, dbv, dWa, dba = (torch.zeros(n, device=DEV) for n in (512, 1, 512 * A, A))
+    ops.pc_deconv_train(N, A, hpd.view(-1), Wv.view(-1), bv, Wa.view(-1), ba, torch.as_tensor(act, dtype=torch.int32, device=DEV),
+                        tgt.view(-1), torch.as_tensor(mask, device=DEV), lam, gs, ls, d_hp, dWv, dbv, dWa, dba, d_dec=d_dec)
+    dd64 = d_dec.double().view(N, 20, 20, 1 + A).permute(0, 3, 1, 2).contiguous()
+    hmask = (hp64 > 0).double()
+
+    def grads(dd_, W_, h_):
+        dh = F.conv2d(dd_, W_, stride=2) * hmask
+        dW = torch.einsum("nkp,ncp->nkc", F.unfold(dd_, 4, stride=2), h_.reshape(N, 32, 81))
+        return dh, dW, dd_.sum((2, 3))
+
+    r_dhp, r_dWn, r_dbn = grads(dd64, Wcat, hp64)
+    s_dhp, s_dWn, s_dbn = grads(dd64.abs(), Wcat.abs(), hp64.abs())
+    to_w = lambda t: t.sum(0).view(1 + A, 4, 4, 32).permute(1, 2, 0, 3)
+    ddmax_f = dd64.abs().amax((1, 2, 3))                                                 # per frame
+    hpmax, wmax = float(hpd.abs().max()), float(Wcat.abs().max())
+    tag = "pc_deconv_train A=%d %s" % (A, which)
+    # the frame's scale comes from max |dL/dQ| >= max |d_dec| (the advantage factors are <= 1 - 1/A): allow that factor
+    slack = 1.0 / (1.0 - 1.0 / A) if A > 1 else 1.0
+    _check_bound(tag + " d_hp", (d_hp.view(N, 9, 9, 32).permute(0, 3, 1, 2).double() - r_dhp).abs(), s_dhp,
+                 (U38 * 2 * slack * wmax * 16 * (1 + A)) * ddmax_f.view(N, 1, 1, 1))
+    got_dW = torch.cat([dWv.view(4, 4, 1, 32), dWa.view(4, 4, A, 32)], 2).double()
+    _check_bound(tag + " dW", (got_dW - to_w(r_dWn)).abs(), to_w(s_dWn), float(U38 * 2 * slack * hpmax * 81 * ddmax_f.sum()))
+    _check_bound(tag + " db", (torch.cat([dbv, dba]).double() - r_dbn.sum(0)).abs(), s_dbn.sum(0), 0.0)
+    if which == "ddrows":       # what the per-frame scale buys: every frame's d_hp within (1) of ITS OWN magnitude
+        rel = ((d_hp.view(N, -1).double() - r_dhp.permute(0, 2, 3, 1).reshape(N, -1)).abs().amax(1) /
+               r_dhp.abs().amax((1, 2, 3)).clamp_min(1e-300))
+        live = torch.as_tensor(mask, device=DEV) != 0
+        margins.record(tag + " worst frame: max |err d_hp| / max |d_hp| of the frame", float(rel[live].max()) / 1e-5, "1e-5")
+        assert float(rel[live].max()) <= 1e-5
 
 
 def test_absmax_slot_is_committed_by_every_producer_variant():

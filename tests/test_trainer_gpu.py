@@ -568,3 +568,42 @@ def test_half_batch_rollout_on_two_streams_is_the_lockstep_rollout(use_lstm, gro
         for k in ("total_loss", "pc_loss", "vr_loss", "rp_loss", "grad_norm"):
             assert abs(a["losses"][k] - b["losses"][k]) <= 1e-5 * max(1.0, abs(a["losses"][k])), k
         np.testing.assert_allclose(b["params"], a["params"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("batch_aux", [True, False])
+def test_one_launch_pixel_control_pass_is_the_two_launch_pass(batch_aux, monkeypatch):
+    """Trainer.fuse_pc_deconv (unreal_pc_deconv_train: loss + backward of the pixel-control deconvolutions in one launch,
+    d_dec on chip under per-frame scales) against the two-launch form (unreal_pc_deconv_fwd + unreal_pc_deconv_bwd, one
+    scale per launch) through whole process() calls, batched and per-branch replay schedule: same rollouts and samples;
+    the first update's losses and gradient agree at the parity bars (the two differ in the rounding of d_dec's lo planes
+    only), parameters after three updates to 1e-5."""
+    from unreal_amd.train.trainer import Trainer
+    B, H, T = 32, 40, 20
+    cfg = _cfg(True, True, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    out = []
+    for fused in (True, False):
+        monkeypatch.setattr(Trainer, "fuse_pc_deconv", fused)
+        monkeypatch.setattr(Trainer, "batch_aux_default", batch_aux)
+        net, applier, tr, draws = _build(cfg, B, seed=11)
+        assert tr.batch_aux == batch_aux
+        while not tr._full:
+            tr.process(None, 0)
+        g, snaps = 0, []
+        for it in range(3):
+            steps, _ = tr.process(None, g)
+            g += steps
+            snaps.append(dict(actions=tr.actions.cpu().numpy().copy(), losses=dict(tr.last_losses),
+                              grads=net.grads.flat.cpu().numpy().copy(), params=net.params.flat.cpu().numpy().copy()))
+        assert ((tr.gws2 if batch_aux else tr.gws).d_dec is None) == fused
+        out.append(snaps)
+    a, b = out[0][0], out[1][0]
+    np.testing.assert_array_equal(a["actions"], b["actions"])
+    for k in ("total_loss", "pc_loss", "grad_norm"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= LOSS_ATOL + LOSS_RTOL * abs(b["losses"][k]), k
+    gmax = float(np.abs(b["grads"]).max())
+    d = float(np.abs(a["grads"] - b["grads"]).max())
+    margins.record("one-launch vs two-launch pixel-control pass: max |d grad| / max |grad| (batch_aux=%s)" % batch_aux,
+                   d / (GRAD_ATOL + GRAD_REL * gmax), "%g + %g rel" % (GRAD_ATOL, GRAD_REL))
+    assert d <= GRAD_ATOL + GRAD_REL * gmax, (d, gmax)
+    np.testing.assert_allclose(out[0][2]["params"], out[1][2]["params"], rtol=1e-5, atol=1e-6)

@@ -160,6 +160,9 @@ def main():
         report("pc_deconv_bwd N=%d" % N,
                timeit(lambda: ops.pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, *g, hp_max=s_hp, ddec_max=s_dd)), flop=2 * 2 * 207360.0 * N,
                bytes_=N * (10368 * 2 + 8000.0))
+        report("pc_deconv_train N=%d (forward loss + backward, one launch)" % N,
+               timeit(lambda: ops.pc_deconv_train(N, A, hp, Wv, bv, Wa, ba, act, tgt, mask, 0.05, 1.0, loss, d_hp, *g,
+                                                  hp_max=s_hp)), flop=3 * 2 * 207360.0 * N, bytes_=N * (10368 * 2 + 1600.0))
 
     if not FILT or FILT in "env":
         ring = ops.Ring(B, 8, DEV)

@@ -69,8 +69,15 @@ items = [
      "gemm_split_nt_kernel<64, 64, true, true, 2, 2", "%.0f GFLOP + gate tensors" % (bptt_flop / G)),
     ("fc 2592->256 of a rollout step (21 x 4096 rows)", ("gemm_split_nt_kernel<64, 64, true, true, 0, 4",), fc_flop, 833,
      "gemm_split_nt_kernel<64, 64, true, true, 0, 4", "%.0f GFLOP" % (fc_flop / G)),
+] + ([
+    # round 4 (late): the training pass of the head is one launch; the forward kernel is left with the bootstrap Q-max
+    ("pc_deconv_train (loss + backward in one launch; before: pc_deconv_fwd training launch + pc_deconv_bwd)", ("pc_deconv_train",),
+     rowsB * 1.24e6, 833, "pc_deconv_train_kernel", "81,920 frames x 1.24 MFLOP, x 22.3 KB"),
+    ("pc_deconv_fwd (bootstrap Q-max)", ("pc_deconv_fwd",), B * 0.41e6, 833, "pc_deconv_fwd_kernel", "4,096 frames x 0.41 MFLOP"),
+] if pick(br, "pc_deconv_train")[0] else [
     ("pc_deconv_bwd", ("pc_deconv_bwd",), rowsB * 0.83e6, 833, "pc_deconv_bwd_kernel", "81,920 frames x 0.83 MFLOP"),
     ("pc_deconv_fwd (2)", ("pc_deconv_fwd",), (rowsB + B) * 0.41e6, 833, "pc_deconv_fwd_kernel", "86,016 frames x 0.41 MFLOP"),
+]) + [
     ("maze_step + policy head (20; fused since round 4)", ("maze_step_kernel",), None, None, "maze_step_kernel", "20 x 4096 actors x 22.8 KB"),
 ]
 out = ["# Per-kernel achieved rates inside `bench.py` (MI355X, round %s)" % tag[1:].lstrip("0"), "",
@@ -86,6 +93,8 @@ for name, subs, flop, ceil, pk, work in items:
     pms = pick(pbr, *subs)[0] if prev else None
     if name.startswith("maze_step") and prev:
         pms += pick(pbr, "policy_step")[0]
+    if name.startswith("pc_deconv_train") and prev:          # the previous round's two launches of the same work
+        pms = pick(pbr, "pc_deconv_bwd")[0] + pick(pbr, "pc_deconv_fwd")[0] * (rowsB / float(rowsB + B))
     listed += ms
     tf = flop / (ms * 1e-3) / 1e12 if flop and ms else None
     busy, hb = pm(pk, "mfma_busy_frac"), pm(pk, "hbm_bytes_per_launch")

@@ -130,8 +130,16 @@ class GradWS(object):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
         self.hp = f(pc_rows * ops.F2_DIM)
         self.d_hp = f(pc_rows * ops.F2_DIM) if own_d_hp else None
-        self.d_dec = f(pc_rows * ops.PC_CELLS * (1 + A))
+        self.d_dec = None            # only the two-launch form of the head's training pass needs it (ensure_d_dec)
         self.pc_R = f(pc_rows * ops.PC_CELLS)
+
+    def ensure_d_dec(self, pc_rows, A):
+        """d(loss)/d(deconv pre-activations) [pc_rows][400][1+A]: the hand-over of unreal_pc_deconv_fwd to unreal_pc_deconv_bwd
+        (655 MB at 81,920 rows; unreal_pc_deconv_train keeps it on chip)."""
+        n = pc_rows * ops.PC_CELLS * (1 + A)
+        if self.d_dec is None or self.d_dec.numel() < n:
+            self.d_dec = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self.d_dec
 
     def ensure_rows(self, rows, B, device):
         """Grow the row-sized temporaries (a per-branch replay pass on a trainer that was sized for the batched one)."""

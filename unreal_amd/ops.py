@@ -717,6 +717,20 @@ def pc_deconv_bwd(N, A, hp, d_dec, Wv, Wa, d_hp, dWv, dbv, dWa, dba, dhp_max=Non
           ptr(dhp_max), ptr(dWv), ptr(dbv), ptr(dWa), ptr(dba))
 
 
+def pc_deconv_train(N, A, hp, Wv, bv, Wa, ba, action, target, mask, lam, grad_scale, loss, d_hp, dWv, dbv, dWa, dba,
+                    dhp_max=None, hp_max=None, d_dec=None):
+    """pc_deconv_fwd (training mode) + pc_deconv_bwd in one launch; d_dec stays on chip (optional output for inspection)."""
+    _chk(hp, "f32", N * F2_DIM); _chk(Wv, "f32", 512); _chk(bv, "f32", 1); _chk(Wa, "f32", 512 * A); _chk(ba, "f32", A)
+    _chk(action, "i32", N); _chk(target, "f32", N * PC_CELLS); _chk(mask, "i32", N); _chk(loss, "f32", 1)
+    _chk(d_hp, "f32", N * F2_DIM); _chk(dWv, "f32", 512); _chk(dbv, "f32", 1); _chk(dWa, "f32", 512 * A); _chk(dba, "f32", A)
+    _chk(dhp_max, "f32", 1, "dhp_max", optional=True); _chk(hp_max, "f32", 1, "hp_max", optional=True)
+    _chk(d_dec, "f32", N * PC_CELLS * (1 + A), optional=True)
+    hp_max = _absmax_of(hp, N, F2_DIM, F2_DIM, hp_max)
+    _call("unreal_pc_deconv_train", N, A, ptr(hp), ptr(hp_max), ptr(Wv), ptr(bv), ptr(Wa), ptr(ba), ptr(action), ptr(target),
+          ptr(mask), float(lam), float(grad_scale), ptr(loss), ptr(d_hp), ptr(dhp_max), ptr(dWv), ptr(dbv), ptr(dWa), ptr(dba),
+          ptr(d_dec))
+
+
 def axpy(alpha, x, y):
     """y += alpha * x (f32 device vectors)."""
     _chk(x, "f32"); _chk(y, "f32", x.numel())

@@ -526,6 +526,34 @@ class Trainer(object):
         ops.seq_mask(B, Ta, self.seq_len, self.seq_mask)
         return net.trunk_forward(self.ring, ws, Ta, B, lar_from_ring=True, save_c1=True)
 
+    # Pixel-control head, training pass: loss + backward of the two deconvolutions in ONE launch (unreal_pc_deconv_train:
+    # d_dec stays on chip, hp is staged once; 22 KB of HBM traffic per frame instead of 49).  False: the two-launch form.
+    fuse_pc_deconv = True
+    keep_d_dec = False       # True: the one-launch form also writes d_dec to gws.d_dec (the full-size tests read it)
+
+    def _pc_deconv_loss_backward(self, gws, rows, mask, d_hp, s_hp):
+        """gws.hp (relu(pc_fc1), max in slot s_hp), self.seq_act, gws.pc_R -> losses[3], d_hp, the deconv parameter
+        gradients; returns the slot holding max |d_hp| (model.py:411-443, 542-557 and their gradients)."""
+        A, net = self.action_size, self.local_network
+        p, g = net.p, net.g
+        s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
+        if self.fuse_pc_deconv:
+            ops.pc_deconv_train(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"], p["b_pc_deconv_a"],
+                                self.seq_act, gws.pc_R, mask, self.pixel_change_lambda, self.grad_scale, self.losses[3:4], d_hp,
+                                g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
+                                hp_max=s_hp, d_dec=gws.ensure_d_dec(rows, A) if self.keep_d_dec else None)
+            return s_dhp
+        s_dd = net.new_slot()              # bound of max |d_dec|: committed by the deconv forward
+        d_dec = gws.ensure_d_dec(rows, A)
+        ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
+                          p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=mask,
+                          lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=d_dec,
+                          loss=self.losses[3:4], hp_max=s_hp, ddec_max=s_dd)
+        ops.pc_deconv_bwd(rows, A, gws.hp, d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
+                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
+                          hp_max=s_hp, ddec_max=s_dd)
+        return s_dhp
+
     def _train_pc(self):
         """[Pixel change] (trainer.py:339-380, model.py:411-443, 542-557)."""
         B, Ta, A, net = self.Bg, self.local_t_max, self.action_size, self.local_network
@@ -540,18 +568,11 @@ class Trainer(object):
                           p["b_pc_deconv_a"], qmax=self.boot_qmax, hp_max=s_bhp)
         ops.pc_returns(self.ring, Ta + 1, self.seq_idx, self.seq_len, self.boot_qmax, self.gamma_pc, gws.pc_R)
         feat, ld = self._aux_forward()
-        s_hp, s_dd = net.new_slot(), net.new_slot()      # max hp (pc_fc1 GEMM) / bound of max |d_dec| (deconv forward)
+        s_hp = net.new_slot()              # max hp: committed by the pc_fc1 GEMM
         net.pc_head_forward(rows, feat, ld, gws.hp, ws=self.aux_ws, hp_max=s_hp)
         ops.gather_i32(self.ring.r_action, self.aux_ws.frame_idx[:rows], self.seq_act)
-        ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
-                          p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask,
-                          lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
-                          loss=self.losses[3:4], hp_max=s_hp, ddec_max=s_dd)
         d_hp = gws.d_f2
-        s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
-        ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
-                          hp_max=s_hp, ddec_max=s_dd)
+        s_dhp = self._pc_deconv_loss_backward(gws, rows, self.seq_mask, d_hp, s_hp)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, ld, d_hp, 2592, g["W_pc_fc1"], 2592,
                               splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
@@ -610,18 +631,11 @@ class Trainer(object):
         feat, ld = net.trunk_forward(self.ring, ws, Ta, 2 * B, lar_from_ring=True, save_c1=True)
         d_feat = gws.d_feat
         # pixel-control head on the even rows
-        s_hp, s_dd = net.new_slot(), net.new_slot()      # max hp (pc_fc1 GEMM) / bound of max |d_dec| (deconv forward)
+        s_hp = net.new_slot()              # max hp: committed by the pc_fc1 GEMM
         net.pc_head_forward(rows, feat, 2 * ld, gws.hp, ws=self.aux2_ws, hp_max=s_hp)
         ops.gather_i32(self.ring.r_action, self.seq_idx2[0][:rows], self.seq_act)
-        ops.pc_deconv_fwd(rows, A, gws.hp, p["W_pc_deconv_v"], p["b_pc_deconv_v"], p["W_pc_deconv_a"],
-                          p["b_pc_deconv_a"], action=self.seq_act, target=gws.pc_R, mask=self.seq_mask2[0],
-                          lam=self.pixel_change_lambda, grad_scale=self.grad_scale, d_dec=gws.d_dec,
-                          loss=self.losses[3:4], hp_max=s_hp, ddec_max=s_dd)
         d_hp = gws.d_hp
-        s_dhp = net.new_slot()             # max |d_hp|: committed by the deconv backward, read by the pc_fc1 dgrad
-        ops.pc_deconv_bwd(rows, A, gws.hp, gws.d_dec, p["W_pc_deconv_v"], p["W_pc_deconv_a"], d_hp,
-                          g["W_pc_deconv_v"], g["b_pc_deconv_v"], g["W_pc_deconv_a"], g["b_pc_deconv_a"], dhp_max=s_dhp,
-                          hp_max=s_hp, ddec_max=s_dd)
+        s_dhp = self._pc_deconv_loss_backward(gws, rows, self.seq_mask2[0], d_hp, s_hp)
         from ..model.model import _splitk
         ops.gemm_split_tn(256, 2592, rows, feat, 2 * ld, d_hp, 2592, g["W_pc_fc1"], 2592,
                           splitk=_splitk(256, 2592, rows), colsum=g["b_pc_fc1"],
