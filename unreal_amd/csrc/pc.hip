@@ -408,13 +408,12 @@ __device__ __forceinline__ void pc_bwd_weight_planes(const float* __restrict__ W
   }
 }
 
-// d_dec of a frame, a thread's two output positions (cell[0..1], >= PC_CELLS: none; 8 channel slots each, channels >= CO zero), split
+// d_dec of a frame, a thread's two output positions (gtid, gtid + 256; 8 channel slots each, channels >= CO zero), split
 // into the planes and stored as ONE 16-byte row per plane; the bias gradient sums ride along
-__device__ __forceinline__ void pc_stage_dd(unsigned char* ddp, const int (&cell)[2], const float (&dd)[2][8], float S_DD,
-                                            float (&adbk)[8]) {
+__device__ __forceinline__ void pc_stage_dd(unsigned char* ddp, int gtid, const float (&dd)[2][8], float S_DD, float (&adbk)[8]) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int pos = cell[h];
+    const int pos = gtid + 256 * h;
     if (pos < PC_CELLS) {
       u32x2p lo[NPLP], hi[NPLP];
       split4p((f32x4){dd[h][0], dd[h][1], dd[h][2], dd[h][3]}, S_DD, lo);
@@ -591,7 +590,6 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
   // threads: a runtime division per element to find its position, three 2-byte LDS writes per element and eight
   // compare-selects for the bias sums -- about as much VALU as the rest of the kernel.
   float pre_dd[2][8];
-  const int own[2] = {gtid, gtid + 256};
   auto load_dd = [&](int frame) {
     const float* src = p.d_dec + (size_t)frame * PC_CELLS * CO;
 #pragma unroll
@@ -609,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
       hp_load(p.hp + (size_t)n0 * F2_DIM, gtid, pre_hp);
       hp_store_planes(hpp, gtid, pre_hp, S_HP);
       load_dd(n0);
-      pc_stage_dd(ddp, own, pre_dd, S_DD, adbk);
+      pc_stage_dd(ddp, gtid, pre_dd, S_DD, adbk);
     }
   }
   for (int n = blockIdx.x; n < p.N; n += stride) {
@@ -626,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void pc_deconv_bwd_kernel(PcBwdArgs p) {
     dhp_max = pc_drain_dhp(dhs, p.d_hp + (size_t)n * F2_DIM, gtid, dhp_max);
     if (has_next) {
       hp_store_planes(hpp, gtid, pre_hp, S_HP);
-      pc_stage_dd(ddp, own, pre_dd, S_DD, adbk);
+      pc_stage_dd(ddp, gtid, pre_dd, S_DD, adbk);
     }
   }
   pc_commit_grads(aw, un_wgrad, adbk, dhp_max, A, p.dWv, p.dWa, p.dbv, p.dba, p.dhp_absmax, s_red, gw, lane, i, q);
@@ -650,9 +648,6 @@ struct PcTrainArgs {
   float* d_dec;             // nullable: the frames' d_dec [N][400][1+A] (tests; the trainer does not ask for it)
 };
 
-#ifndef PC_TRAIN_WAVE_LOCAL
-#define PC_TRAIN_WAVE_LOCAL 1      // 0: cells dealt by thread id, a block barrier between deconvolution and dueling (A/B: profiles/r04_ab_summary.md 3d)
-#endif
 template <int COT> struct TrainLds {
   static constexpr int DS = COT | 1;
   static constexpr int UNI = PC_CELLS * DS * 4 > F2_DIM * 4 ? PC_CELLS * DS * 4 : F2_DIM * 4;   // dec, later dhs
@@ -703,21 +698,6 @@ __global__ __launch_bounds__(256, TrainLds<COT>::WGS) void pc_deconv_train_kerne
   for (int k = 0; k < 8; ++k) adbk[k] = 0.f;
   float dhp_max = 0.f, loss_acc = 0.f;
 
-  // the two output cells whose channels this thread combines
-  int cell[2];
-#if PC_TRAIN_WAVE_LOCAL
-  // ... are cells its OWN wave produces: deconv_packed gives wave gw the base-position tiles gw and gw + 4 (16 positions x
-  // 4 output parities = 64 cells each), lane -> (position i, parity q)
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int tile = gw + 4 * t, m = tile * 16 + i;
-    cell[t] = (tile < 7 && m < 100) ? (2 * (m / 10) + (q >> 1)) * 20 + 2 * (m % 10) + (q & 1) : PC_CELLS;
-  }
-#else
-  cell[0] = gtid;
-  cell[1] = gtid + 256;
-#endif
-
   const int stride = gridDim.x;
   f32x4 pre[HP_V];
   __syncthreads();   // zero fills visible
@@ -730,21 +710,12 @@ __global__ __launch_bounds__(256, TrainLds<COT>::WGS) void pc_deconv_train_kerne
     const bool has_next = nn < p.N;
     __syncthreads();  // [S0] hp planes of frame n staged; the previous frame's d_hp drained
     if (has_next) hp_load(p.hp + (size_t)nn * F2_DIM, gtid, pre);
-    const float tg[2] = {p.target[(size_t)n * PC_CELLS + min(cell[0], PC_CELLS - 1)],
-                         p.target[(size_t)n * PC_CELLS + min(cell[1], PC_CELLS - 1)]};
+    const float tg[2] = {p.target[(size_t)n * PC_CELLS + gtid], p.target[(size_t)n * PC_CELLS + min(gtid + 256, PC_CELLS - 1)]};
     const int act = p.action[n];
     const bool on = p.mask[n] != 0;
     if (two_nt) deconv_packed<true, DS>(hpp, wdp, uni, gw, i, q, CO, bias, un_fwd);
     else deconv_packed<false, DS>(hpp, wdp, uni, gw, i, q, CO, bias, un_fwd);
-#if PC_TRAIN_WAVE_LOCAL
-    // no block barrier: the cells this wave combines are the ones it has just written, and a wave's LDS operations
-    // execute in issue order (the fences only keep the compiler from moving the reads above the writes)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
     __syncthreads();  // [S1] pre-activations complete
-#endif
     // dueling combine, loss and d_dec of this thread's two output positions (pc_deconv_fwd_kernel's arithmetic)
     float dd[2][8];
     float fmx = 0.f;
@@ -752,7 +723,7 @@ __global__ __launch_bounds__(256, TrainLds<COT>::WGS) void pc_deconv_train_kerne
     for (int pi = 0; pi < 2; ++pi) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) dd[pi][k] = 0.f;
-      const int pos = cell[pi];
+      const int pos = gtid + 256 * pi;
       if (pos < PC_CELLS) {
         const float* d = uni + pos * DS;
         const float vpre = d[0];
@@ -788,7 +759,7 @@ __global__ __launch_bounds__(256, TrainLds<COT>::WGS) void pc_deconv_train_kerne
     __syncthreads();  // [S2] the frame's max |dq|
     const float S_DD = pow2_scale(fmaxf(fmaxf(red[40], red[41]), fmaxf(red[42], red[43])));
     const float inv_dd = pow2_inv(S_DD);
-    pc_stage_dd(ddp, cell, dd, S_DD, adbk);
+    pc_stage_dd(ddp, gtid, dd, S_DD, adbk);
     __syncthreads();  // [S3] d_dec planes staged; every read of dec done
     pc_dgrad_frame(hpp, ddp, wbp, uni, gw, i, q, inv_dd * pow2_inv(S_W));
     {
