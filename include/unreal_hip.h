@@ -168,6 +168,14 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
                              const void* mask /* fp32 [M][ldm] (RELU_MASK: keep where > 0) or uint16 bit words [M][ldm]
                                                  (RELU_BITS: keep column j where bit j % 16 of word j / 16 is set) */,
                              int ldm, int flags, int splitk, void* stream);
+/* The same product for FEW ROWS and a LONG K (the fc 2592 -> 256 of a rollout step at <= 1024 rows): the K range runs as
+ * `splitk` >= 2 slabs in separate workgroups, their partial products go to `partials` (>= splitk * M * pad4(N) floats,
+ * 16-byte aligned), a second launch adds them in slab order (deterministic), applies bias / ReLU (flags: 0 or 1) and
+ * commits max |C| to c_absmax (nullable). */
+int unreal_gemm_f32_split_nt_slabs(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3,
+                                   int ldw, long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax,
+                                   const float* bias, int flags, int splitk, float* partials, long partial_floats,
+                                   void* stream);
 /* splitk > 1 needs UNREAL_GEMM_ATOMIC (K slabs added into a pre-initialised C with fp32 atomics; no ReLU / mask /
  * ACCUM then).  Measured at the per-step shapes (4096 rows): 4096x256x2592 61 -> 50 us at splitk 4, 4096x256x1024
  * slower (the atomics cost what the extra workgroups buy), so the trainer keeps splitk = 1 there. */

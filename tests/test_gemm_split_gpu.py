@@ -274,3 +274,50 @@ def test_shadow_set_refresh_is_the_per_matrix_refresh():
         ss.refresh()
         for m in single:
             m.refresh()
+
+
+@pytest.mark.parametrize("M,N,K,S", [(8, 256, 2592, 14), (1, 256, 2592, 16), (160, 256, 2592, 8), (512, 256, 2592, 8),
+                                     (1000, 256, 2592, 4), (70, 250, 1100, 5), (33, 64, 4000, 16)])
+def test_few_rows_slab_product(M, N, K, S):
+    """unreal_gemm_f32_split_nt_slabs (the fc 2592 -> 256 of a rollout step at <= 1024 rows: K slabs in separate workgroups,
+    partial products added in slab order by a second launch with bias / ReLU / max |C|): the one-launch kernel's bound
+    against fp64, an error no larger than the one-launch kernel's on the same data (x 1.5: the sum order differs), max |C|
+    committed exactly, padding columns untouched, and -- unlike the atomic split-K epilogue -- bit-reproducible."""
+    from unreal_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    lda, ldb, ldc = (K + 7) // 4 * 4, (K + 11) // 4 * 4, (N + 4) if N % 4 == 0 else N + 3
+    A = rs.uniform(-1, 1, size=(M, lda)); B = rs.uniform(-1, 1, size=(N, ldb)) * 0.05
+    A[:, :K] *= rs.choice([1.0, 1e-3, 37.0], size=(M, 1))
+    bias = rs.uniform(-1, 1, size=N)
+    Ad, Bd, bd = dev(A), dev(B), dev(bias)
+    ref = Ad[:, :K].double() @ Bd[:, :K].double().t() + bd.double()
+    scale = Ad[:, :K].double().abs() @ Bd[:, :K].double().abs().t()
+    W = ops.SplitWeights(Bd, N, K, ldb, transpose=False)
+    part = torch.empty(S * M * ((N + 3) // 4 * 4) + 8, device=DEV)
+    for flags in (0, ops.GEMM_RELU):
+        want = torch.relu(ref) if flags else ref
+        C = torch.full((M, ldc), 7.0, device=DEV); slot = torch.zeros(1, device=DEV)
+        ops.gemm_split_nt_slabs(M, N, K, Ad, lda, W, C, ldc, part, S, bias=bd, flags=flags, c_max=slot)
+        err = (C[:, :N].double() - want).abs()
+        assert bool((err <= 3e-7 * scale + 1e-6).all()), float((err / (scale + 1e-30)).max())
+        assert float(C[:, N:].min()) == 7.0 == float(C[:, N:].max())
+        assert float(slot[0]) == float(C[:, :N].abs().max())
+        C1 = torch.full((M, ldc), 7.0, device=DEV)
+        ops.gemm_split_nt(M, N, K, Ad, lda, W, C1, ldc, bias=bd, flags=flags)
+        err1 = (C1[:, :N].double() - want).abs()
+        assert float((err ** 2).mean().sqrt()) <= 1.5 * float((err1 ** 2).mean().sqrt()) + 1e-9
+        C2 = torch.full((M, ldc), 7.0, device=DEV)
+        part.fill_(float("nan"))                       # nothing may depend on what the buffer held
+        ops.gemm_split_nt_slabs(M, N, K, Ad, lda, W, C2, ldc, part, S, bias=bd, flags=flags)
+        assert torch.equal(C2, C)
+    with pytest.raises((RuntimeError, ValueError)):     # other epilogue flags belong to the one-launch kernel
+        ops.gemm_split_nt_slabs(M, N, K, Ad, lda, W, C, ldc, part, S, flags=ops.GEMM_ACCUM)
+    with pytest.raises((RuntimeError, ValueError)):     # partials too small
+        ops.gemm_split_nt_slabs(M, N, K, Ad, lda, W, C, ldc, part[:M * N], S)
+
+
+def test_slab_count_covers_the_small_update_shapes():
+    from unreal_amd import ops
+    assert ops.slab_count(4096, 256, 2592) == 0                                                # enough tiles already
+    assert [ops.slab_count(m, 256, 2592) for m in (1, 8, 512, 1024, 2048)] == [8, 8, 8, 4, 2]
+    assert ops.slab_count(512, 2592, 256) == 0                                                 # short K

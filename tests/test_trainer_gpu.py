@@ -607,3 +607,33 @@ def test_one_launch_pixel_control_pass_is_the_two_launch_pass(batch_aux, monkeyp
                    d / (GRAD_ATOL + GRAD_REL * gmax), "%g + %g rel" % (GRAD_ATOL, GRAD_REL))
     assert d <= GRAD_ATOL + GRAD_REL * gmax, (d, gmax)
     np.testing.assert_allclose(out[0][2]["params"], out[1][2]["params"], rtol=1e-5, atol=1e-6)
+
+
+def test_few_rows_fc_slabs_is_the_one_launch_fc(monkeypatch):
+    """UnrealModel.fc_few_rows_slabs (the fc product of <= 1024-row launches as K slabs + ordered sum) against the one-launch
+    kernel through whole grouped process() calls (B = 64, G = 8: 8-row rollout steps, 160 / 320-row replay passes): identical
+    rollouts (actions, rewards, step counts), losses and gradient at the parity bars, parameters after three updates to 1e-5."""
+    from unreal_amd.model.model import UnrealModel
+    B, H, T = 64, 40, 20
+    cfg = _cfg(True, True, H, T)
+    cfg["initial_learning_rate"] = 7.0711e-4
+    out = []
+    for slabs in (True, False):
+        monkeypatch.setattr(UnrealModel, "fc_few_rows_slabs", slabs)
+        net, applier, tr, draws = _build(cfg, B, seed=13, groups=8)
+        while not tr._full:
+            tr.process(None, 0)
+        g, snaps = 0, []
+        for it in range(3):
+            steps, _ = tr.process(None, g)
+            g += steps
+            snaps.append(dict(actions=tr.actions.cpu().numpy().copy(), rewards=tr.rewards.cpu().numpy().copy(), steps=steps,
+                              losses=dict(tr.last_losses), params=net.params.flat.cpu().numpy().copy()))
+        out.append(snaps)
+    a, b = out[0][0], out[1][0]
+    np.testing.assert_array_equal(a["actions"], b["actions"])
+    np.testing.assert_array_equal(a["rewards"], b["rewards"])
+    assert a["steps"] == b["steps"]
+    for k in ("total_loss", "pc_loss", "vr_loss", "rp_loss", "grad_norm"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= LOSS_ATOL + LOSS_RTOL * abs(b["losses"][k]), k
+    np.testing.assert_allclose(out[0][2]["params"], out[1][2]["params"], rtol=1e-5, atol=1e-6)

@@ -94,7 +94,8 @@ struct SplitArgs {
   int flags;
   int vecA;
   int nbx, nby;
-  int splitk, ktiles_per_split;        // > 1 only with FLAG_ATOMIC: K slabs added into C with fp32 atomics
+  int splitk, ktiles_per_split;        // > 1: K slabs, added into C with fp32 atomics (FLAG_ATOMIC) or ...
+  long slab_stride;                    // ... != 0: stored as partial products, slab s at C + s * slab_stride (unreal_gemm_f32_split_nt_slabs)
   // fused LSTM step (EPI == 1): C is the gate buffer [M][1024] (in: input-half pre-activations, out: activated gates)
   const float* c_prev; float* c_out; float* h_out; int ld_h;
   // DUAL: A operand = [A (K1 valid columns, k < K1pad) | A2 (K - K1pad columns)]
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256 * KW, KW == 1 ? ((BM == 64 && BN == 128) ? 4 : 
   const int bx = s2 % p.nbx, by = (s2 / p.nbx) * 8 + xcd;
   if (by >= p.nby) return;
   const int m0 = by * BM, n0 = bx * BN;
+  if (EPI == 0) p.C += (size_t)slab * p.slab_stride;    // partial products of the K slabs side by side (0: one C)
   const int kt_base = slab * p.ktiles_per_split;
   const int nkt = min((p.K + BK - 1) / BK - kt_base, p.ktiles_per_split);
   if (nkt <= 0) return;
@@ -1118,6 +1120,48 @@ __global__ __launch_bounds__(256) void multi_split_kernel(const MultiSplitDesc* 
 
 }  // namespace
 
+// K slabs of unreal_gemm_f32_split_nt_slabs -> C: the S partial products of an element are added in slab order (fixed:
+// bit-reproducible, unlike the atomic epilogue), then bias / ReLU, and max |C| leaves with one commit per workgroup.
+// VEC: four columns per thread (N, ldp, ldc multiples of 4, 16-byte aligned pointers).
+template <bool VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int M, int N, int S, const float* __restrict__ part, long slab_stride,
+                                                            int ldp, const float* __restrict__ bias, int relu,
+                                                            float* __restrict__ C, int ldc, float* c_absmax) {
+  constexpr int W = VEC ? 4 : 1;
+  const int ncol = (N + W - 1) / W;
+  const long total = (long)M * ncol;
+  float mx = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / ncol), col = (int)(e % ncol) * W;
+    const float* src = part + (size_t)row * ldp + col;
+    if (VEC) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      for (int sl = 1; sl < S; ++sl) v += *reinterpret_cast<const f32x4*>(src + (size_t)sl * slab_stride);
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (relu) v[k] = fmaxf(v[k], 0.f);
+        mx = fmaxf(mx, fabsf(v[k]));
+      }
+      *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
+    } else {
+      float v = src[0];
+      for (int sl = 1; sl < S; ++sl) v += src[(size_t)sl * slab_stride];
+      if (bias) v += bias[col];
+      if (relu) v = fmaxf(v, 0.f);
+      mx = fmaxf(mx, fabsf(v));
+      C[(size_t)row * ldc + col] = v;
+    }
+  }
+  if (c_absmax) {                       // block-uniform
+    __shared__ float wm[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x < 64) absmax_commit(c_absmax, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+  }
+}
+
 extern "C" {
 
 int unreal_absmax_f32(int rows, int cols, const float* x, int ld, float* slot, void* stream) {
@@ -1150,9 +1194,11 @@ int unreal_split_f16x2(int rows, int cols, const float* src, int ld_src, int tra
   return unreal_launch_status();
 }
 
-int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3, int ldw,
-                             long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax, const float* bias,
-                             const void* mask, int ldm, int flags, int splitk, void* stream) {
+// slab_stride != 0 (unreal_gemm_f32_split_nt_slabs): the splitk K slabs leave as plain partial products, slab s at
+// C + s * slab_stride; *splitk_eff receives the number of slabs actually used
+static int split_nt_launch(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3, int ldw,
+                           long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax, const float* bias,
+                           const void* mask, int ldm, int flags, int splitk, long slab_stride, int* splitk_eff, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W3 || !C) return UNREAL_EINVAL;
   if (SPLIT_NT_MODE == MODE_F16X2 && (!a_absmax || !w_absmax)) return UNREAL_EINVAL;
   const int kpad = (K + BK - 1) / BK * BK;
@@ -1164,7 +1210,7 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   if ((flags & FLAG_RELU_BITS) && (!mask || ldm < (N + 15) / 16 || (flags & FLAG_RELU_MASK))) return UNREAL_EINVAL;
   if ((flags & FLAG_ATOMIC) && (flags & (FLAG_RELU | FLAG_RELU_MASK | FLAG_RELU_BITS | FLAG_ACCUM))) return UNREAL_EINVAL;
   if (splitk < 1) splitk = 1;
-  if (splitk > 1 && !(flags & FLAG_ATOMIC)) return UNREAL_EINVAL;
+  if (splitk > 1 && !(flags & FLAG_ATOMIC) && !slab_stride) return UNREAL_EINVAL;
   // the atomic epilogue adds partial tiles into C: no workgroup ever sees a finished element, so max |C| cannot be
   // committed there -- a slot left at 0 would silently turn the consumer's scale into 1
   if ((flags & FLAG_ATOMIC) && c_absmax) return UNREAL_EINVAL;
@@ -1183,6 +1229,8 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
     if (splitk > nk) splitk = nk;
     a.ktiles_per_split = (nk + splitk - 1) / splitk;
     a.splitk = (nk + a.ktiles_per_split - 1) / a.ktiles_per_split;
+    a.slab_stride = a.splitk > 1 ? slab_stride : 0;
+    if (splitk_eff) *splitk_eff = a.splitk;
   }
   const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128) * a.splitk;
   // Experiment knobs of round 4 (tools/exp/gemm_ab.py, profiles/r04_ab_summary.md; all default 0, none of their kernels is
@@ -1248,6 +1296,44 @@ int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const
   return unreal_launch_status();
 }
 
+int unreal_gemm_f32_split_nt(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3, int ldw,
+                             long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax, const float* bias,
+                             const void* mask, int ldm, int flags, int splitk, void* stream) {
+  return split_nt_launch(M, N, K, A, lda, a_absmax, W3, ldw, plane_stride, w_absmax, C, ldc, c_absmax, bias, mask, ldm, flags,
+                         splitk, 0, nullptr, stream);
+}
+
+// Few rows, long K (the fc 2592 -> 256 of a rollout step at <= 1024 rows: 4-64 tiles of 81 dependent K steps on a 256-CU
+// chip): the K range is cut into `splitk` slabs that run as separate workgroups and leave their partial products in
+// `partials` (splitk x M x pad4(N) floats), a second launch adds the slabs of every element in slab order, applies bias /
+// ReLU (flags: 0 or FLAG_RELU) and commits max |C|.  Deterministic (no atomics); the sum order differs from the one-launch
+// kernel's, the per-product arithmetic does not.
+int unreal_gemm_f32_split_nt_slabs(int M, int N, int K, const float* A, int lda, const float* a_absmax, const uint16_t* W3,
+                                   int ldw, long plane_stride, const float* w_absmax, float* C, int ldc, float* c_absmax,
+                                   const float* bias, int flags, int splitk, float* partials, long partial_floats,
+                                   void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !C || !partials || ldc < N || (flags & ~FLAG_RELU) || splitk < 2) return UNREAL_EINVAL;
+  const int ldp = (N + 3) & ~3;
+  const long slab_stride = (long)M * ldp;
+  const int nk = (K + BK - 1) / BK;
+  if (splitk > nk) splitk = nk;
+  if (partial_floats < slab_stride * splitk || (((uintptr_t)partials) & 15)) return UNREAL_EINVAL;
+  int S = 1;
+  const int rc = split_nt_launch(M, N, K, A, lda, a_absmax, W3, ldw, plane_stride, w_absmax, partials, ldp, nullptr, nullptr,
+                                 nullptr, 0, 0, splitk, slab_stride, &S, stream);
+  if (rc != UNREAL_OK) return rc;
+  const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((((uintptr_t)C) | ((uintptr_t)bias)) & 15) == 0;
+  const long items = (long)M * (vec ? N / 4 : N);
+  const int blocks = (int)min((items + 255) / 256, (long)1024);
+  if (vec)
+    hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, S, partials,
+                       slab_stride, ldp, bias, flags & FLAG_RELU, C, ldc, c_absmax);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M, N, S, partials,
+                       slab_stride, ldp, bias, flags & FLAG_RELU, C, ldc, c_absmax);
+  return unreal_launch_status();
+}
+
 int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float* x_absmax, const float* h_prev, int ld_hprev,
                          const uint16_t* W3, int ldw, long plane_stride, const float* w_absmax, float* gates, const float* bias,
                          const float* c_prev, float* c_out, float* h_out, int ld_h, void* stream) {
@@ -1266,7 +1352,7 @@ int unreal_lstm_step_fwd(int rows, const float* x, int ldx, int Kx, const float*
   a.dh_above = nullptr; a.dc_io = nullptr; a.gates_act = nullptr; a.c_new = nullptr; a.dpre = nullptr;
   // A = [x | h_prev]: |h| < 1 by construction (tanh * sigmoid), so the scale covers max(1, max |x|)
   a.a_absmax = x ? x_absmax : nullptr; a.a_floor = 1.f; a.w_absmax = w_absmax; a.c_absmax0 = nullptr; a.c_absmax1 = nullptr;
-  a.splitk = 1; a.ktiles_per_split = a.K / BK;
+  a.splitk = 1; a.ktiles_per_split = a.K / BK; a.slab_stride = 0;
   a.nbx = 16; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
   const bool vec_h = ((ld_hprev & 3) == 0) && ((((uintptr_t)h_prev) & 15) == 0);
@@ -1327,7 +1413,7 @@ int unreal_lstm_bptt_step(int rows, const float* d_gates, const float* a_absmax,
   a.A2 = nullptr; a.lda2 = 0; a.K1 = 1024; a.K1pad = 0;
   a.dh_above = dh_above; a.dc_io = dc_io; a.gates_act = gates_act; a.c_new = c_new; a.dpre = dpre;
   a.a_absmax = a_absmax; a.a_floor = 0.f; a.w_absmax = w_absmax; a.c_absmax0 = dpre_absmax0; a.c_absmax1 = dpre_absmax1;
-  a.splitk = 1; a.ktiles_per_split = 1024 / BK;
+  a.splitk = 1; a.ktiles_per_split = 1024 / BK; a.slab_stride = 0;
   a.nbx = 4; a.nby = (rows + 63) / 64;
   const int grid = a.nbx * ((a.nby + 7) / 8 * 8);
   const long tiles = (long)a.nbx * a.nby;

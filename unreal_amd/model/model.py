@@ -89,6 +89,7 @@ class PathWS(object):
     def __init__(self, rows, B, device, save_c1=True, lstm=True, xld=XLD):
         f = lambda n: torch.empty(n, dtype=torch.float32, device=device)
         self.rows, self.B, self.xld = rows, B, xld
+        self.fc_partials = {}     # stream handle -> K-slab partial products of the fc product at few rows (encode_rows)
         self.s_x = self.s_f2 = self.s_x_cur = self.s_c1 = None     # absmax slots of the rows' LSTM input x / conv output (UnrealModel.encode_rows, per pass)
         self.pass_id = None
         self.frame_idx = torch.zeros(rows, dtype=torch.int32, device=device)
@@ -363,8 +364,20 @@ class UnrealModel(object):
                         p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2,
                         c1_max=ws.s_c1 if c1 is not None else None)
         sh = self.shadow
-        ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
-                          flags=ops.GEMM_RELU, a_max=s_f2, c_max=s_fc)
+        nslab = ops.slab_count(nrows, 256, 2592) if self.fc_few_rows_slabs else 0
+        if nslab:
+            # few rows (a group's rollout step, a small update's replay pass): 4-64 tiles of 81 dependent K steps would
+            # leave most of the chip idle -- 2-8 K slabs in separate workgroups + an ordered sum (one partials buffer per stream:
+            # blocks of one workspace may be encoded on several streams at once)
+            key = torch.cuda.current_stream(f2.device).cuda_stream
+            part = ws.fc_partials.get(key)
+            if part is None or part.numel() < nslab * nrows * 256:
+                part = ws.fc_partials[key] = torch.empty(nslab * nrows * 256, dtype=torch.float32, device=f2.device)
+            ops.gemm_split_nt_slabs(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, part, nslab,
+                                    bias=p["b_base_fc1"], flags=ops.GEMM_RELU, a_max=s_f2, c_max=s_fc)
+        else:
+            ops.gemm_split_nt(nrows, 256, 2592, f2, 2592, sh["fc1_fwd"], xcat, self.xld, bias=p["b_base_fc1"],
+                              flags=ops.GEMM_RELU, a_max=s_f2, c_max=s_fc)
         ws.s_x_cur = s_fc          # max over the fc columns; the other columns of x are added below where they can exceed 1
         if own:
             ops.absmax(1, 1, s_f2, 1, ws.s_f2)
@@ -419,6 +432,9 @@ class UnrealModel(object):
     # recurrence and each step multiplies only h (the round-1 schedule).  False: every step multiplies [x | h] by the
     # whole kernel -- at 4096 rows a step is bound by operand bytes, not FLOPs, and the hoisted form writes and re-reads
     # 16 MB of pre-activations per step on top (measured: 52 -> 30 us per step of a sequence, tools/bench_kernels.py lstm).
+    # fc 2592 -> 256 at <= ops.FEW_ROWS (2048) rows as K slabs + ordered sum (unreal_gemm_f32_split_nt_slabs); False: the
+    # one-launch kernel at every row count (A/B: profiles/r04_ab_summary.md 3e)
+    fc_few_rows_slabs = True
     hoist_lstm_x = False
     relu_bits = True           # fc dgrad masks with the encoder's 1-bit ReLU pattern instead of re-reading f2 (849 MB per branch)
     fuse_bptt = True           # BPTT: recurrent dgrad + the earlier step's gate backward in one launch (lstm_bptt_step)

@@ -563,6 +563,32 @@ def gemm_split_nt(M, N, K, A, lda, W, C, ldc, bias=None, mask=None, ldm=0, flags
           ptr(c_max), ptr(bias), ptr(mask), ldm, flags, splitk)
 
 
+FEW_ROWS = 2048        # at most this many rows: a long-K product has too few tiles for the chip (gemm_split_nt_slabs)
+
+
+def slab_count(M, N, K):
+    """K slabs for gemm_split_nt_slabs, by the same-process A/B at N = 256, K = 2592 (tools/exp/fc_slabs_ab.py,
+    profiles/r04_ab_summary.md 3e): 8 up to 32 tiles of 64 x 64 (<= 512 rows), 4 up to 64, 2 up to 128 (2048 rows); from 4096
+    rows on the one-launch kernel wins.  0 = use the one-launch kernel."""
+    if M > FEW_ROWS or K < 1024:
+        return 0
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    return 8 if tiles <= 32 else 4 if tiles <= 64 else 2 if tiles <= 128 else 0
+
+
+def gemm_split_nt_slabs(M, N, K, A, lda, W, C, ldc, partials, splitk, bias=None, flags=0, a_max=None, c_max=None):
+    """gemm_split_nt for few rows and a long K: `splitk` K slabs in separate workgroups -> partials (>= splitk * M * pad4(N)
+    floats), added in slab order by a second launch that applies bias / ReLU and commits max |C| (deterministic)."""
+    if W.N != N or W.K != K:
+        raise ValueError("split weights are [%d,%d], GEMM wants [%d,%d]" % (W.N, W.K, N, K))
+    _chk(A, "f32", (M - 1) * lda + K, "A"); _chk(C, "f32", (M - 1) * ldc + N, "C")
+    _chk(bias, "f32", N, "bias", optional=True); _chk(partials, "f32", splitk * M * ((N + 3) // 4 * 4), "partials")
+    _chk(a_max, "f32", 1, "a_max", optional=True); _chk(c_max, "f32", 1, "c_max", optional=True)
+    a_max = _absmax_of(A, M, K, lda, a_max)
+    _call("unreal_gemm_f32_split_nt_slabs", M, N, K, ptr(A), lda, ptr(a_max), ptr(W.planes), W.ldw, W.plane, ptr(W.wmax), ptr(C),
+          ldc, ptr(c_max), ptr(bias), flags, splitk, ptr(partials), partials.numel())
+
+
 def gemm_split_tn(M, N, K, A, lda, B, ldb, C, ldc, splitk=1, colsum=None, a_max=None, b_max=None):
     """C[M,N] += A[K,M]^T @ B[K,N] (wgrad; fp32-grade on the fp16 matrix cores, split-K atomics into C);
     colsum[N] += column sums of B (the bias gradient of the same layer) when given.
