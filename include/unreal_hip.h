@@ -138,7 +138,17 @@ int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float
                        uint16_t* relu_bits /*nullable [N][81][2]: bit c of word [n][pos][h] = f2[n][pos][16h + c] > 0,
                                              i.e. bit (j % 16) of word j / 16 of row n; UNREAL_GEMM_RELU_BITS reads it */,
                        float* f2_absmax /*nullable absmax slot: max of f2_out, see unreal_absmax_f32*/,
-                       float* c1_absmax /*nullable absmax slot: max of the conv1 activation (c1_out)*/, void* stream);
+                       float* c1_absmax /*nullable absmax slot: max of the conv1 activation (c1_out)*/,
+                       const void* prepared /*nullable: block written by unreal_encoder_prepare for THESE W1, b1, W2 and
+                                              frame_scale; without it every workgroup derives scales and operand
+                                              fragments itself (identical results)*/,
+                       void* stream);
+/* The weights' share of unreal_encoder_fwd's prologue, once per weight update instead of once per workgroup and launch:
+ * power-of-two scales of W1 / W2 / the conv1 planes and the fp16 hi + lo MFMA operand fragments of both convolutions ->
+ * `prepared` (UNREAL_ENCODER_PREPARED_BYTES, 16-byte aligned). */
+#define UNREAL_ENCODER_PREPARED_BYTES 45072
+int unreal_encoder_prepare(const float* W1, const float* b1, const float* W2, float frame_scale, void* prepared,
+                           long prepared_bytes, void* stream);
 /* c1_absmax / d2_absmax: absmax slots covering c1_saved / d2 (the kernel keeps both as fp16 hi + lo planes with one
  * power-of-two scale per tensor, like the split GEMMs; the round-2 operand format needed none). */
 int unreal_encoder_bwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W2,

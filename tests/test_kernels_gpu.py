@@ -928,3 +928,35 @@ def test_encoder_fwd_is_bit_reproducible(ops):
     assert torch.equal(c2, a2[torch.as_tensor(perm, device=DEV)]) and torch.equal(c1_, a1[torch.as_tensor(perm, device=DEV)])
     d2, d1 = run(np.arange(5))                                  # five workgroups instead of 512
     assert torch.equal(d2, a2[:5]) and torch.equal(d1, a1[:5])
+
+
+@pytest.mark.parametrize("N,save_c1", [(700, True), (3, True), (40, False)])
+def test_encoder_fwd_with_prepared_weights_is_the_same_kernel(ops, N, save_c1):
+    """unreal_encoder_prepare (the weights' share of the forward prologue -- scales and MFMA operand fragments -- once per
+    weight update) + unreal_encoder_fwd(prepared=...) against the launch that derives them per workgroup: every output
+    bit for bit (f2, the saved conv1 activation, the ReLU bit words, both absmax slots); a block made for other weights
+    changes the result (it is really read)."""
+    rs = np.random.RandomState(N)
+    P = {k: dev(v, torch.float32) for k, v in _enc_params(7).items()}
+    fr = dev(rs.randint(0, 256, size=(N, 84, 84, 3)).astype(np.uint8).reshape(-1))
+    idx = dev(rs.permutation(N).astype(np.int32))
+    scale = 1.0 / 255.0
+
+    def run(prepared):
+        f2 = torch.zeros(N * 2592, device=DEV); c1 = torch.zeros(N * 6400, device=DEV) if save_c1 else None
+        bits = torch.zeros(N * ops.RELU_WORDS, dtype=torch.int16, device=DEV) if save_c1 else None
+        s2, s1 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+        ops.encoder_fwd(fr, idx, scale, P["W_base_conv1"], P["b_base_conv1"], P["W_base_conv2"], P["b_base_conv2"], f2, c1,
+                        relu_bits=bits, f2_max=s2, c1_max=s1 if save_c1 else None, prepared=prepared)
+        return f2, c1, bits, s2, s1
+
+    prep = ops.encoder_prepare(P["W_base_conv1"], P["b_base_conv1"], P["W_base_conv2"], scale)
+    assert prep.numel() == ops.ENC_PREPARED_BYTES
+    a, b = run(None), run(prep)
+    for x, y in zip(a, b):
+        assert (x is None and y is None) or torch.equal(x, y)
+    assert float(a[3]) == float(a[0].max()) > 0
+    other = ops.encoder_prepare(P["W_base_conv1"] * 1.5, P["b_base_conv1"], P["W_base_conv2"], scale)
+    assert not torch.equal(run(other)[0], a[0])
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.encoder_prepare(P["W_base_conv1"], P["b_base_conv1"], P["W_base_conv2"], scale, prepared=prep[:1000])

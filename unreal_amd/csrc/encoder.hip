@@ -412,83 +412,67 @@ __device__ unsigned long long g_fstamp[4][8];
 #define FSTAMP(k)
 #endif
 
-template <bool BITS>
-__global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
-                                                             const int* __restrict__ frame_idx, float scale,
-                                                             const float* __restrict__ W1, const float* __restrict__ b1,
-                                                             const float* __restrict__ W2, const float* __restrict__ b2,
-                                                             float* __restrict__ c1_out, float* __restrict__ f2_out,
-                                                             uint16_t* __restrict__ relu_bits, float* f2_absmax,
-                                                             float* c1_absmax) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
-  float f2_max = 0.f, c1_max = 0.f;            // max of the outputs this lane has stored (they are >= 0)
-  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
-  const int i = lane & 15, q = lane >> 4;
-  uint8_t* fr = smem;
-  unsigned char* xp = smem + FWD_X;
-  unsigned char* pp = smem + FWD_P;
-  const unsigned lds_fr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int nt = gw & 1, kh = gw >> 1;         // conv2: this wave's n-tile and K half
+// ---- the weights' share of the forward prologue: scales and operand fragments.  Every workgroup of every launch used to
+// redo it (two reductions over W1 / W2, 80 strided loads and their splits per thread: ~6 of the ~18 us a launch costs before
+// its first frame); unreal_encoder_prepare runs it ONCE per weight update into a 45 KB block that the launches read back
+// with 20 coalesced 16-byte loads per thread.  Same device functions on both routes: identical registers, identical outputs.
+struct EncFwdScales { float S_W1, S_W2, S_C1; };
+constexpr int ENC_PREP_W1 = 1;                                  // u32x4 index: [kc][t][lane]
+constexpr int ENC_PREP_W2 = ENC_PREP_W1 + 6 * NPLF * 64;        // [c][t][thread]
+constexpr int ENC_PREP_VECS = ENC_PREP_W2 + 4 * NPLF * 256;     // x 16 bytes
 
-  // fp16x2: power-of-two scales of W1, W2 (maxima reduced here, once) and of the c1 planes (from the bound above)
-  float S_W1 = 1.f, S_W2 = 1.f, S_C1 = 1.f;
-  if (ENC_FWD_F16) {
-    float* red = reinterpret_cast<float*>(smem);            // [16] L1 norm of W1 per channel, [16] max |W1|, [17] max |W2|
-    if (tid < 18) red[tid] = 0.f;
-    __syncthreads();
-    float l1 = 0.f, m1 = 0.f, m2 = 0.f;
-    const int c = tid & 15;
-    for (int k = tid >> 4; k < 192; k += 16) { const float w = fabsf(W1[k * 16 + c]); l1 += w; m1 = fmaxf(m1, w); }
-    for (int e = tid; e < 8192; e += 256) m2 = fmaxf(m2, fabsf(W2[e]));
-    // channel L1 norms in a FIXED order (a float atomicAdd's order is not: workgroups could then land on different sides
-    // of a power of two and round their c1 planes differently): the wave's four lanes of channel c by a shuffle tree, the
-    // four waves' partials by a fixed sum below.  (The maxima are order-independent: atomicMax.)
-    l1 += __shfl_xor(l1, 16, 64);
-    l1 += __shfl_xor(l1, 32, 64);
-    if (lane < 16) red[32 + gw * 16 + lane] = l1;
-    atomicMax(reinterpret_cast<unsigned int*>(red + 16), __float_as_uint(m1));
-    atomicMax(reinterpret_cast<unsigned int*>(red + 17), __float_as_uint(m2));
-    __syncthreads();
-    float bound = 0.f;
+// red: 96 floats of LDS; all 256 threads; three barriers
+__device__ __forceinline__ EncFwdScales enc_fwd_scales(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                       const float* __restrict__ W2, float scale, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
+  // red: [16] max |W1|, [17] max |W2|, [32..95] the waves' partial L1 norms of W1 per channel
+  if (tid < 18) red[tid] = 0.f;
+  __syncthreads();
+  float l1 = 0.f, m1 = 0.f, m2 = 0.f;
+  const int c = tid & 15;
+  for (int k = tid >> 4; k < 192; k += 16) { const float w = fabsf(W1[k * 16 + c]); l1 += w; m1 = fmaxf(m1, w); }
+  for (int e = tid; e < 8192; e += 256) m2 = fmaxf(m2, fabsf(W2[e]));
+  // channel L1 norms in a FIXED order (a float atomicAdd's order is not: workgroups could then land on different sides
+  // of a power of two and round their c1 planes differently): the wave's four lanes of channel c by a shuffle tree, the
+  // four waves' partials by a fixed sum below.  (The maxima are order-independent: atomicMax.)
+  l1 += __shfl_xor(l1, 16, 64);
+  l1 += __shfl_xor(l1, 32, 64);
+  if (lane < 16) red[32 + gw * 16 + lane] = l1;
+  atomicMax(reinterpret_cast<unsigned int*>(red + 16), __float_as_uint(m1));
+  atomicMax(reinterpret_cast<unsigned int*>(red + 17), __float_as_uint(m2));
+  __syncthreads();
+  float bound = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float l1c = (red[32 + k] + red[48 + k]) + (red[64 + k] + red[80 + k]);
-      bound = fmaxf(bound, 255.f * fabsf(scale) * l1c + fabsf(b1[k]));
-    }
-    S_W1 = pow2_scale(red[16]);
-    S_W2 = pow2_scale(red[17]);
-    S_C1 = pow2_scale(bound);
-    __syncthreads();
+  for (int k = 0; k < 16; ++k) {
+    const float l1c = (red[32 + k] + red[48 + k]) + (red[64 + k] + red[80 + k]);
+    bound = fmaxf(bound, 255.f * fabsf(scale) * l1c + fabsf(b1[k]));
   }
-  // conv1: un-scales W1 and applies the byte scale in one factor
-  const float scale1 = scale * pow2_inv(S_W1);
-  const float inv_c2 = pow2_inv(S_C1) * pow2_inv(S_W2);    // conv2: exact (both powers of two; |exponents| <= 100 each
-                                                           // cannot meet here: c1's bound and W2's maximum are O(1))
-  u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
-  if (ENC_FWD_F16) {
+  const EncFwdScales sc = {pow2_scale(red[16]), pow2_scale(red[17]), pow2_scale(bound)};
+  __syncthreads();
+  return sc;
+}
+
+// conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
+__device__ __forceinline__ void enc_fwd_w1_frags(const float* __restrict__ W1, float S_W1, int q, int i, u32x4v (&w1)[6][3]) {
 #pragma unroll
-    for (int kc = 0; kc < 6; ++kc) {
-      f32x4 lo4, hi4;
+  for (int kc = 0; kc < 6; ++kc) {
+    f32x4 lo4, hi4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        lo4[e] = W1[(32 * kc + 8 * q + e) * 16 + i];
-        hi4[e] = W1[(32 * kc + 8 * q + 4 + e) * 16 + i];
-      }
-      u32x2v lo[3], hi[3];
-      split4_fop(lo4, S_W1, lo);
-      split4_fop(hi4, S_W1, hi);
-#pragma unroll
-      for (int t = 0; t < NPLF; ++t) w1[kc][t] = (u32x4v){lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+    for (int e = 0; e < 4; ++e) {
+      lo4[e] = W1[(32 * kc + 8 * q + e) * 16 + i];
+      hi4[e] = W1[(32 * kc + 8 * q + 4 + e) * 16 + i];
     }
-  } else {
-    load_w1_bf16x3(W1, q, i, w1);
-  }
-  int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
+    u32x2v lo[3], hi[3];
+    split4_fop(lo4, S_W1, lo);
+    split4_fop(hi4, S_W1, hi);
 #pragma unroll
-  for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
-  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * q);
-  // conv2: B[k = 32kc + 8q + j][col = n = 16nt + i] = W2[(tap = 2kc + (q>>1)) * 16 + 8(q&1) + j][n], kc = 4kh + c
-  fop8 w2[4][NPLF];
+    for (int t = 0; t < NPLF; ++t) w1[kc][t] = (u32x4v){lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
+  }
+}
+
+// conv2: B[k = 32kc + 8q + j][col = n = 16nt + i] = W2[(tap = 2kc + (q>>1)) * 16 + 8(q&1) + j][n], kc = 4kh + c
+__device__ __forceinline__ void enc_fwd_w2_frags(const float* __restrict__ W2, float S_W2, int q, int i, int nt, int kh,
+                                                 fop8 (&w2)[4][NPLF]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int k0 = 32 * (4 * kh + c) + 8 * q;
@@ -506,6 +490,93 @@ __global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_
       const u32x4 w4 = {lo[t][0], lo[t][1], hi[t][0], hi[t][1]};
       w2[c][t] = __builtin_bit_cast(fop8, w4);
     }
+  }
+}
+
+// one workgroup: the prepared block of encoder_fwd_kernel (header: S_W1, S_W2, S_C1, the frame scale it was made for)
+__global__ __launch_bounds__(256) void encoder_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
+                                                              const float* __restrict__ W2, float scale, u32x4* __restrict__ prep) {
+  __shared__ float red[96];
+  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
+  const int i = lane & 15, q = lane >> 4, nt = gw & 1, kh = gw >> 1;
+  const EncFwdScales sc = enc_fwd_scales(W1, b1, W2, scale, red);
+  if (tid == 0) prep[0] = (u32x4){__float_as_uint(sc.S_W1), __float_as_uint(sc.S_W2), __float_as_uint(sc.S_C1), __float_as_uint(scale)};
+  u32x4v w1[6][3];
+  enc_fwd_w1_frags(W1, sc.S_W1, q, i, w1);
+  if (gw == 0) {
+#pragma unroll
+    for (int kc = 0; kc < 6; ++kc)
+#pragma unroll
+      for (int t = 0; t < NPLF; ++t) prep[ENC_PREP_W1 + (kc * NPLF + t) * 64 + lane] = w1[kc][t];
+  }
+  fop8 w2[4][NPLF];
+  enc_fwd_w2_frags(W2, sc.S_W2, q, i, nt, kh, w2);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < NPLF; ++t) prep[ENC_PREP_W2 + (c * NPLF + t) * 256 + tid] = __builtin_bit_cast(u32x4, w2[c][t]);
+}
+
+template <bool BITS>
+__global__ __launch_bounds__(256, 2) void encoder_fwd_kernel(int N, const uint8_t* __restrict__ frames,
+                                                             const int* __restrict__ frame_idx, float scale,
+                                                             const float* __restrict__ W1, const float* __restrict__ b1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2,
+                                                             float* __restrict__ c1_out, float* __restrict__ f2_out,
+                                                             uint16_t* __restrict__ relu_bits, float* f2_absmax,
+                                                             float* c1_absmax, const u32x4* __restrict__ prep) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
+  float f2_max = 0.f, c1_max = 0.f;            // max of the outputs this lane has stored (they are >= 0)
+  const int tid = threadIdx.x, lane = tid & 63, gw = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  uint8_t* fr = smem;
+  unsigned char* xp = smem + FWD_X;
+  unsigned char* pp = smem + FWD_P;
+  const unsigned lds_fr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int nt = gw & 1, kh = gw >> 1;         // conv2: this wave's n-tile and K half
+
+  // fp16x2: power-of-two scales of W1, W2 and of the c1 planes (from the bound above) -- read from the prepared block
+  // (unreal_encoder_prepare: once per weight update) or reduced here, once per workgroup
+  float S_W1 = 1.f, S_W2 = 1.f, S_C1 = 1.f;
+  if (ENC_FWD_F16) {
+    if (prep) {
+      const u32x4 h = prep[0];
+      S_W1 = __uint_as_float(h[0]); S_W2 = __uint_as_float(h[1]); S_C1 = __uint_as_float(h[2]);
+    } else {
+      const EncFwdScales sc = enc_fwd_scales(W1, b1, W2, scale, reinterpret_cast<float*>(smem));
+      S_W1 = sc.S_W1; S_W2 = sc.S_W2; S_C1 = sc.S_C1;
+    }
+  }
+  // conv1: un-scales W1 and applies the byte scale in one factor
+  const float scale1 = scale * pow2_inv(S_W1);
+  const float inv_c2 = pow2_inv(S_C1) * pow2_inv(S_W2);    // conv2: exact (both powers of two; |exponents| <= 100 each
+                                                           // cannot meet here: c1's bound and W2's maximum are O(1))
+  u32x4v w1[6][3];                             // conv1: A[row = channel i][k = 32kc + 8q + j], NPLF terms
+  if (ENC_FWD_F16) {
+    if (prep) {
+#pragma unroll
+      for (int kc = 0; kc < 6; ++kc)
+#pragma unroll
+        for (int t = 0; t < NPLF; ++t) w1[kc][t] = prep[ENC_PREP_W1 + (kc * NPLF + t) * 64 + lane];
+    } else {
+      enc_fwd_w1_frags(W1, S_W1, q, i, w1);
+    }
+  } else {
+    load_w1_bf16x3(W1, q, i, w1);
+  }
+  int koff[6];                                 // byte offset of patch element k = 32kc + 8q inside the frame
+#pragma unroll
+  for (int kc = 0; kc < 6; ++kc) koff[kc] = ((32 * kc + 8 * q) / 24) * FRAME_ROW_BYTES + (32 * kc + 8 * q) % 24;
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * q);
+  // conv2: B[k = 32kc + 8q + j][col = n = 16nt + i] = W2[(tap = 2kc + (q>>1)) * 16 + 8(q&1) + j][n], kc = 4kh + c
+  fop8 w2[4][NPLF];
+  if (ENC_FWD_F16 && prep) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t = 0; t < NPLF; ++t) w2[c][t] = __builtin_bit_cast(fop8, prep[ENC_PREP_W2 + (c * NPLF + t) * 256 + tid]);
+  } else {
+    enc_fwd_w2_frags(W2, S_W2, q, i, nt, kh, w2);
   }
   const float bias2 = b2[16 * nt + i];
   // conv2 fragment of (position tile mt, K chunk c): byte offset inside a c1 plane of row (2oy + dy)*20 + 2ox + dx, channel
@@ -692,15 +763,26 @@ extern "C" {
 
 int unreal_encoder_fwd(int N, const uint8_t* frames, const int* frame_idx, float frame_scale, const float* W1,
                        const float* b1, const float* W2, const float* b2, float* c1_out, float* f2_out,
-                       uint16_t* relu_bits, float* f2_absmax, float* c1_absmax, void* stream) {
+                       uint16_t* relu_bits, float* f2_absmax, float* c1_absmax, const void* prepared, void* stream) {
   if (N <= 0 || !frames || !frame_idx || !W1 || !b1 || !W2 || !b2 || !f2_out) return UNREAL_EINVAL;
+  if ((((uintptr_t)prepared) & 15) || (prepared && !ENC_FWD_F16)) return UNREAL_EINVAL;
+  const u32x4* prep = static_cast<const u32x4*>(prepared);
   int blocks = min(N, 512);             // one frame per workgroup at a time, two workgroups per CU
   if (relu_bits)
     hipLaunchKernelGGL(encoder_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax, prep);
   else
     hipLaunchKernelGGL(encoder_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, N, frames, frame_idx,
-                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax);
+                       frame_scale, W1, b1, W2, b2, c1_out, f2_out, relu_bits, f2_absmax, c1_absmax, prep);
+  return unreal_launch_status();
+}
+
+int unreal_encoder_prepare(const float* W1, const float* b1, const float* W2, float frame_scale, void* prepared,
+                           long prepared_bytes, void* stream) {
+  if (!W1 || !b1 || !W2 || !prepared || (((uintptr_t)prepared) & 15) || !ENC_FWD_F16) return UNREAL_EINVAL;
+  if (prepared_bytes < (long)ENC_PREP_VECS * 16) return UNREAL_EINVAL;
+  hipLaunchKernelGGL(encoder_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, W1, b1, W2, frame_scale,
+                     static_cast<u32x4*>(prepared));
   return unreal_launch_status();
 }
 

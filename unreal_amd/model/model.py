@@ -255,6 +255,25 @@ class UnrealModel(object):
                           pc_fc1_dgrad=S(p["W_pc_fc1"], 256, 2592, 2592, False))
             self._shadow, self._shadow_set = sh, ss
         self._shadow_set.refresh()
+        if self.prepare_encoder:
+            # the conv weights' share of encoder_fwd's prologue (scales + MFMA operand fragments), once per update instead
+            # of once per workgroup of each of the ~24 encoder launches that follow
+            p = self.p
+            self._enc_prep = ops.encoder_prepare(p["W_base_conv1"], p["b_base_conv1"], p["W_base_conv2"], self.frame_scale,
+                                                 self._enc_prep)
+
+    # False: every encoder_fwd workgroup derives scales and fragments itself (identical results; A/B: r04_ab_summary.md 3f)
+    prepare_encoder = True
+    _enc_prep = None
+
+    @property
+    def enc_prepared(self):
+        """Block of ops.encoder_prepare for the current conv weights and self.frame_scale (None: prepare_encoder off)."""
+        if not self.prepare_encoder:
+            return None
+        if self._enc_prep is None or self._shadow_stale:
+            self.refresh_shadows()
+        return self._enc_prep
 
     @property
     def shadow(self):
@@ -362,7 +381,7 @@ class UnrealModel(object):
         s_f2, s_fc = slots if slots is not None else ((self.new_slot(), self.new_slot()) if own else (ws.s_f2, ws.s_x))
         ops.encoder_fwd(ring.frames, idx, self.frame_scale, p["W_base_conv1"], p["b_base_conv1"],
                         p["W_base_conv2"], p["b_base_conv2"], f2, c1, relu_bits=bits, f2_max=s_f2,
-                        c1_max=ws.s_c1 if c1 is not None else None)
+                        c1_max=ws.s_c1 if c1 is not None else None, prepared=self.enc_prepared)
         sh = self.shadow
         nslab = ops.slab_count(nrows, 256, 2592) if self.fc_few_rows_slabs else 0
         if nslab:

@@ -318,18 +318,34 @@ def reset_state(B, terminal_end, c, h):
 
 
 # ---- network -------------------------------------------------------------------------------------
+ENC_PREPARED_BYTES = 45072          # include/unreal_hip.h: UNREAL_ENCODER_PREPARED_BYTES
+
+
+def encoder_prepare(W1, b1, W2, scale, prepared=None):
+    """The weights' share of encoder_fwd's prologue (scales + MFMA operand fragments) -> `prepared` (uint8
+    [ENC_PREPARED_BYTES]); valid for these W1 / b1 / W2 values and this frame scale.  Returns the block."""
+    _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192)
+    if prepared is None:
+        prepared = torch.empty(ENC_PREPARED_BYTES, dtype=torch.uint8, device=W1.device)
+    _chk(prepared, "u8", ENC_PREPARED_BYTES, "prepared")
+    _call("unreal_encoder_prepare", ptr(W1), ptr(b1), ptr(W2), float(scale), ptr(prepared), prepared.numel())
+    return prepared
+
+
 def encoder_fwd(frames, frame_idx, scale, W1, b1, W2, b2, f2_out, c1_out=None, n_frames_pool=None, relu_bits=None,
-                f2_max=None, c1_max=None):
+                f2_max=None, c1_max=None, prepared=None):
     """relu_bits: optional int16 [N * RELU_WORDS], bit (j % 16) of word j / 16 of a frame = f2[j] > 0.
-    f2_max: optional absmax slot that receives max f2 (the A scale of the fc GEMM that follows)."""
+    f2_max: optional absmax slot that receives max f2 (the A scale of the fc GEMM that follows).
+    prepared: optional block from encoder_prepare(W1, b1, W2, scale) -- same results, shorter prologue per launch."""
     N = frame_idx.numel()
     _chk(frames, "u8"); _chk(frame_idx, "i32", N)
     _chk(W1, "f32", 3072); _chk(b1, "f32", 16); _chk(W2, "f32", 8192); _chk(b2, "f32", 32)
     _chk(f2_out, "f32", N * F2_DIM); _chk(c1_out, "f32", N * C1_DIM, optional=True)
     _chk(relu_bits, "i16", N * RELU_WORDS, "relu_bits", optional=True)
     _chk(f2_max, "f32", 1, "f2_max", optional=True); _chk(c1_max, "f32", 1, "c1_max", optional=True)
+    _chk(prepared, "u8", ENC_PREPARED_BYTES, "prepared", optional=True)
     _call("unreal_encoder_fwd", N, ptr(frames), ptr(frame_idx), float(scale), ptr(W1), ptr(b1), ptr(W2), ptr(b2),
-          ptr(c1_out), ptr(f2_out), ptr(relu_bits), ptr(f2_max), ptr(c1_max))
+          ptr(c1_out), ptr(f2_out), ptr(relu_bits), ptr(f2_max), ptr(c1_max), ptr(prepared))
 
 
 def encoder_bwd(frames, frame_idx, scale, W2, c1_saved, d2, dW1, db1, dW2, db2, c1_max=None, d2_max=None):

@@ -657,7 +657,8 @@ class Trainer(object):
         ops.replay_sample_rp(self.ring, self.rp_coin, self.rp_u, ws.frame_idx[:3 * B], self.rp_class, self.rp_mode)
         s_c1 = net.new_slot()              # max of the conv1 activation: the c1 scale of the conv backward below
         ops.encoder_fwd(self.ring.frames, ws.frame_idx[:3 * B], net.frame_scale, p["W_base_conv1"],
-                        p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1, c1_max=s_c1)
+                        p["b_base_conv1"], p["W_base_conv2"], p["b_base_conv2"], ws.f2, ws.c1, c1_max=s_c1,
+                        prepared=net.enc_prepared)
         ops.linear_small_fwd(B, 7776, 3, ws.f2, 7776, p["W_rp_fc1"], p["b_rp_fc1"], self.rp_logits, 3)
         ops.rp_loss_grad(B, self.rp_logits, self.rp_class, self.grad_scale, None, self.rp_dlogits,
                          self.losses[5:6])
