@@ -61,6 +61,10 @@ __device__ __forceinline__ uint32_t render_byte(int idx, int ax, int ay) {
 // the step kernel VALU-bound at 1.6 TB/s) and streams it out for each of its actors; the agent block -- 12 rows of 36
 // contiguous bytes (0,1,0)x12, never on a wall cell -- is patched in afterwards as 9 dwords per row.
 constexpr int kActorsPerGroup = 8;
+#ifndef MAZE_APG_BIG
+#define MAZE_APG_BIG 8          // actors per workgroup of the step kernel at > 1024 actors (A/B: tools/exp/maze_apg_ab.py)
+#endif
+constexpr int kStepActorsBig = MAZE_APG_BIG;
 
 __device__ __forceinline__ void build_wall_image(uint4* img) {
   for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) {
@@ -502,7 +506,7 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
              score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
              nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
@@ -522,7 +526,7 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
              lar_col0, A, idx_base_actor, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
@@ -546,7 +550,7 @@ int unreal_maze_policy_rollout_step(int B, int H1, const float* X, int ldx, cons
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
              lar_col0, A, idx_base_actor, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, actions_out};
   if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(maze_step_kernel<kActorsPerGroup>, dim3((B + kActorsPerGroup - 1) / kActorsPerGroup), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
 
