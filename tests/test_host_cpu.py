@@ -185,6 +185,23 @@ def test_wgrad_splitk_is_a_multiple_of_8_at_trainer_shapes():
     assert _splitk(256, 1024, 60) == 1 and _splitk(2592, 256, 40) == 1        # tiny test batches: no split
 
 
+def test_few_rows_slab_rule_and_new_entries_reject_bad_arguments(built):
+    """ops.slab_count (which launches of the fc product run as K slabs + ordered sum) is host logic; the round-4 entry
+    points refuse null / undersized buffers before any launch."""
+    from unreal_amd import _lib, ops
+    assert [ops.slab_count(m, 256, 2592) for m in (1, 8, 512, 513, 1024, 2048, 2049, 4096)] == [8, 8, 8, 4, 4, 2, 0, 0]
+    assert ops.slab_count(512, 2592, 256) == 0 and ops.slab_count(512, 256, 1023) == 0       # short K: nothing to cut
+    L = _lib.lib()
+    with pytest.raises(_lib.UnrealLibError):      # no partials buffer
+        L.call("unreal_gemm_f32_split_nt_slabs", 8, 256, 2592, None, 2592, None, None, 2592, 0, None, None, 256, None, None, 0, 8,
+               None, 0, None)
+    with pytest.raises(_lib.UnrealLibError):      # null block
+        L.call("unreal_encoder_prepare", None, None, None, 1.0, None, 0, None)
+    with pytest.raises(_lib.UnrealLibError):      # N = 0
+        L.call("unreal_pc_deconv_train", 0, 4, *([None] * 9), 0.05, 1.0, *([None] * 8), None)
+    assert ops.ENC_PREPARED_BYTES == 45072
+
+
 def test_smoke_entry_can_import_its_test_helpers():
     """__graft_entry__.smoke() borrows helpers from tests/test_trainer_gpu.py, importing it as `tests.test_trainer_gpu` from a
     process whose sys.path holds the repo root only (the driver's call): every module-level import of that file must
