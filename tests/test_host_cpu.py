@@ -202,6 +202,15 @@ def test_few_rows_slab_rule_and_new_entries_reject_bad_arguments(built):
     assert ops.ENC_PREPARED_BYTES == 45072
 
 
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the map from the reference's calls to the C ABI: an entry point it does not mention is one a
+    maintainer cannot find."""
+    from unreal_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _lib.parse_header() if n not in text and n.replace("unreal_philox_", "_") not in text]
+    assert not missing, missing
+
+
 def test_smoke_entry_can_import_its_test_helpers():
     """__graft_entry__.smoke() borrows helpers from tests/test_trainer_gpu.py, importing it as `tests.test_trainer_gpu` from a
     process whose sys.path holds the repo root only (the driver's call): every module-level import of that file must
