@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "exp", "build")
 VARIANTS = {"apg8": ["-DMAZE_APG_BIG=8"], "apg4": ["-DMAZE_APG_BIG=4"], "apg2": ["-DMAZE_APG_BIG=2"], "apg16": ["-DMAZE_APG_BIG=16"]}
+if "--tiny" in sys.argv:        # <= 64 actors: one actor per workgroup (product) against two
+    VARIANTS = {"tiny1": ["-DMAZE_APG_TINY=1"], "tiny2": ["-DMAZE_APG_TINY=2"]}
 
 
 def so_of(v):
@@ -39,8 +41,8 @@ def use(v):
 
 
 DEV = "cuda:0"
-for B in (2048, 4096, 8192):
-    use("apg8")
+for B in ((1, 8, 16, 64) if "--tiny" in sys.argv else (2048, 4096, 8192)):
+    use(next(iter(libs)))
     ring = ops.Ring(B, 8, DEV)
     ops.maze_reset(ring)
     acts = torch.randint(0, 4, (B,), dtype=torch.int32, device=DEV)

@@ -65,6 +65,10 @@ constexpr int kActorsPerGroup = 8;
 #define MAZE_APG_BIG 8          // actors per workgroup of the step kernel at > 1024 actors (A/B: tools/exp/maze_apg_ab.py)
 #endif
 constexpr int kStepActorsBig = MAZE_APG_BIG;
+#ifndef MAZE_APG_TINY
+#define MAZE_APG_TINY 1         // actors per workgroup at <= 64 actors (a small update's rollout step: one actor per workgroup)
+#endif
+constexpr int kStepActorsTiny = MAZE_APG_TINY;
 
 __device__ __forceinline__ void build_wall_image(uint4* img) {
   for (int c = threadIdx.x; c < FRAME_BYTES / 16; c += blockDim.x) {
@@ -143,8 +147,8 @@ struct StepArgs {
 };
 
 // APG actors per workgroup: 8 when the batch fills the chip (the wall image is built once per workgroup: ~2.5 us of VALU),
-// 2 for small batches (grouped updates: 512 / 64 actors per launch), where 8 actors in a row per workgroup were 20 of the
-// launch's 23 us and most CUs had no workgroup at all
+// 2 for small batches (grouped updates: 512 actors per launch), where 8 actors in a row per workgroup were 20 of the
+// launch's 23 us and most CUs had no workgroup at all, 1 at <= 64 actors (an 8-actor update: 8 workgroups instead of 4)
 template <int APG>
 __global__ __launch_bounds__(256) void maze_step_kernel(StepArgs p) {
   __shared__ uint4 wall_img[FRAME_BYTES / 16];
@@ -505,7 +509,8 @@ int unreal_maze_step(int B, int H1, const int* actions, const int* active, int* 
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, reset_on_terminal, track_score, nullptr, nullptr, nullptr, nullptr, nullptr,
              nullptr, 0, 0, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  if (B <= 64) hipLaunchKernelGGL(maze_step_kernel<kStepActorsTiny>, dim3((B + kStepActorsTiny - 1) / kStepActorsTiny), dim3(256), 0, (hipStream_t)stream, p);
+  else if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
@@ -525,7 +530,8 @@ int unreal_maze_rollout_step(int B, int H1, const int* actions, int* pos, int* l
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
              lar_col0, A, idx_base_actor, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  if (B <= 64) hipLaunchKernelGGL(maze_step_kernel<kStepActorsTiny>, dim3((B + kStepActorsTiny - 1) / kStepActorsTiny), dim3(256), 0, (hipStream_t)stream, p);
+  else if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
@@ -549,7 +555,8 @@ int unreal_maze_policy_rollout_step(int B, int H1, const float* X, int ldx, cons
              r_terminal, r_last_action, r_last_reward, r_pc, out_reward, out_terminal, episode_reward,
              score_out, score_valid, 1, 1, active, active_log_t, n_steps, terminal_end, next_idx, next_lar, lar_ld,
              lar_col0, A, idx_base_actor, X, ldx, Wp, bp, Wv, bv, u, pi_out, v_out, actions_out};
-  if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
+  if (B <= 64) hipLaunchKernelGGL(maze_step_kernel<kStepActorsTiny>, dim3((B + kStepActorsTiny - 1) / kStepActorsTiny), dim3(256), 0, (hipStream_t)stream, p);
+  else if (B <= 1024) hipLaunchKernelGGL(maze_step_kernel<2>, dim3((B + 1) / 2), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(maze_step_kernel<kStepActorsBig>, dim3((B + kStepActorsBig - 1) / kStepActorsBig), dim3(256), 0, (hipStream_t)stream, p);
   return unreal_launch_status();
 }
